@@ -1,0 +1,124 @@
+"""CPU: the C oracle (oracle/gsr_oracle.c) against golden vectors captured from the real reference
+(tools/make_golden.py).  This is what pins the oracle; the GPU tests then compare HIP vs oracle."""
+import numpy as np
+import pytest
+
+from conftest import golden_columns, load_golden, psnr
+from oracle import cpu_oracle as orc
+
+import gsr_amd
+from gsr_amd import synthetic, utils
+
+
+def _cam(g, prefix=""):
+    return orc.camera(g[prefix + "qvec"], g[prefix + "tvec"], float(g["fx_full"]), float(g["fy_full"]),
+                      int(g["cam_width"]), int(g["cam_height"]), int(g["width"]), int(g["height"]))
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def test_f1_camera_matrices():
+    g = load_golden("f1_unit.npz")
+    cam = _cam(g)
+    w2c = np.array(cam.w2c, np.float32).reshape(4, 4)
+    assert np.array_equal(w2c, g["w2c_T"])                      # bit-exact: rasterize.py:59-77,:361
+    assert np.array_equal(w2c.T, g["w2c_M"])
+    full_ref = (g["w2c_T"].astype(np.float32) @ g["proj_P"].T.astype(np.float32))
+    full = np.array(cam.full_proj, np.float32).reshape(4, 4)
+    np.testing.assert_allclose(full[:, [0, 1, 3]], full_ref[:, [0, 1, 3]], rtol=0, atol=0)
+    np.testing.assert_allclose(full, full_ref, rtol=2e-7)
+    assert np.float32(g["tan_fov_x"]) == np.float32(cam.tan_fov_x)
+    assert np.float32(1.3 * float(g["tan_fov_x"])) == np.float32(cam.lim_x)
+    assert np.float32(float(g["focals"][0]) / 2) == np.float32(cam.focal_x)
+    inv = np.linalg.inv(g["w2c_T"].astype(np.float64))[3, :3]
+    np.testing.assert_allclose(np.array(cam.cam_center), inv, rtol=1e-6, atol=1e-7)
+
+
+def test_f1_sh_packing():
+    g = load_golden("f1_unit.npz")
+    assert np.array_equal(utils.sh_columns_to_array(golden_columns(g)), g["sh"])   # utils.py:10-31
+
+
+def test_f1_intermediates():
+    g = load_golden("f1_unit.npz")
+    packed = utils.pack_gaussians(golden_columns(g))
+    pre = orc.preprocess(packed, _cam(g))
+    assert _rel(pre["cov3d"], g["cov3d"]) < 1e-6
+    assert _rel(pre["cam_means"], g["cam_means"]) < 1e-6
+    assert _rel(pre["rgb"], g["rgb"]) < 1e-6
+    assert _rel(pre["opacity"], g["opacity"]) < 1e-6
+    vis = g["cam_means"][:, 2] >= 0.2
+    assert _rel(pre["cov2d"][vis], g["cov2d"][vis]) < 2e-5
+    assert _rel(pre["screen_means"], g["screen_means"]) < 1e-5
+    assert _rel(pre["sigmas"], g["sigmas"]) < 2e-4
+    assert np.array_equal(pre["tile_bboxes"], g["tile_bboxes"])
+    assert np.array_equal(pre["pixel_bboxes"], g["pixel_bboxes"])
+
+
+@pytest.mark.parametrize("name,floor_db", [("f1_unit.npz", 120.0), ("f2_small.npz", 120.0)])
+def test_image_matches_reference(name, floor_db):
+    g = load_golden(name)
+    packed = utils.pack_gaussians(golden_columns(g))
+    cam = _cam(g)
+    pre = orc.preprocess(packed, cam)
+    order = orc.depth_order(pre["cam_means"])
+    screen, T, drawn = orc.composite(order, pre, cam.width, cam.height)
+    img = screen.transpose(1, 0, 2)
+    assert drawn == len(g["draw_order"])
+    # drawn order == the reference's (no depth ties in the fixture)
+    mine = [int(i) for i in order if (np.prod(pre["pixel_bboxes"][i, 2:] - pre["pixel_bboxes"][i, :2]) != 0
+                                       and np.all(pre["sigmas"][i] != 0))]
+    assert mine == [int(i) for i in g["draw_order"]]
+    assert psnr(img, g["image"]) >= floor_db
+    assert np.abs(img - g["image"]).max() < 1e-5
+    # Q1: last row / column stay black
+    assert not img[-1].any() and not img[:, -1].any()
+    # whole-frame entry point and threaded banding give the same bits
+    img2, drawn2 = orc.render(packed, cam, threads=1)
+    img3, _ = orc.render(packed, cam, threads=4)
+    assert drawn2 == drawn and np.array_equal(img2, img) and np.array_equal(img3, img)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_f3_edge_cases(tag):
+    g = load_golden("f3_edge.npz")
+    packed = utils.pack_gaussians(golden_columns(g))
+    cam = _cam(g, prefix=tag + "_")
+    pre = orc.preprocess(packed, cam)
+    assert np.array_equal(pre["pixel_bboxes"], g[tag + "_pixel_bboxes"])
+    assert np.array_equal(pre["tile_bboxes"], g[tag + "_tile_bboxes"])
+    assert _rel(pre["rgb"], g[tag + "_rgb"]) < 1e-6
+    # Q2: exact zeros in the conic are reproduced exactly (they gate the skip at rasterize.py:441)
+    assert np.array_equal(pre["sigmas"] == 0, g[tag + "_sigmas"] == 0)
+    order = orc.depth_order(pre["cam_means"])
+    screen, T, drawn = orc.composite(order, pre, cam.width, cam.height)
+    img = screen.transpose(1, 0, 2)
+    assert drawn == len(g[tag + "_draw_order"])
+    assert psnr(img, g[tag + "_image"]) >= 110.0
+    assert bool(g["q4_keyerror"])
+
+
+def test_f3_q2_axis_aligned_gaussian_is_skipped():
+    g = load_golden("f3_edge.npz")
+    assert 0 not in set(int(i) for i in g["a_draw_order"])      # gaussian 0: on-axis, axis-aligned -> sigma_xy == 0
+    assert g["a_sigmas"][0, 2] == 0 and g["a_sigmas"][0, 0] != 0
+
+
+def test_f4_medium_regenerated_inputs():
+    g = load_golden("f4_medium.npz")
+    cols = synthetic.mip360_like(int(g["n"]), int(g["seed"]))
+    for i in range(3):
+        cols[f"scale_{i}"] = (cols[f"scale_{i}"] + np.float32(float(g["scale_shift"]))).astype(np.float32)
+    checksum = sum(float(np.asarray(v, np.float64).sum()) for v in cols.values())
+    assert checksum == float(g["ply_checksum"]), "synthetic generator drifted from the one that made the fixture"
+    packed = utils.pack_gaussians(cols)
+    img, drawn = orc.render(packed, _cam(g), threads=None)
+    assert drawn == int(g["n_drawn"])
+    y0, x0 = int(g["crop_y0"]), int(g["crop_x0"])
+    assert psnr(img[y0:y0 + 256, x0:x0 + 256], g["crop"]) >= 110.0
+    assert psnr(img[::4, ::4], g["decimated"]) >= 110.0
+    np.testing.assert_allclose(img.astype(np.float64).sum(axis=(1, 2)), g["row_sums"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(img.astype(np.float64).sum(axis=(0, 2)), g["col_sums"], rtol=1e-5, atol=1e-4)
