@@ -1,0 +1,161 @@
+/*
+ * gsr.h — C ABI of libgsr.so, the MI355X (gfx950) forward rasterizer for 3D Gaussian Splatting.
+ *
+ * Boundary: the reference (arnaudstiegler/torch-gaussian-splatting-rasterizer)
+ * has no FFI of its own — its "render call" is the body of rasterize.py:315-478.  This header is what a
+ * binding for that path binds: every entry point names the reference lines it replaces.  Rules:
+ *   - extern "C", POD structs, plain pointers and sizes; no C++/torch types; no exceptions cross.
+ *   - every call returns int: GSR_OK or a negative GsrStatus; gsr_last_error() gives thread-local text.
+ *   - the CALLER owns all device memory (inputs, outputs, one scratch workspace sized by
+ *     gsr_workspace_bytes); the library never allocates on the hot path and holds no global state,
+ *     so calls with distinct workspaces/streams may run concurrently.
+ *   - all device work is enqueued on the caller's hipStream_t (passed as void*); nothing synchronises
+ *     except gsr_read_stats.
+ *   - fp32 throughout (the reference's arithmetic type); device pointers unless marked [host].
+ */
+#ifndef GSR_H
+#define GSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_VERSION 100 /* 0.1.0 */
+
+typedef enum GsrStatus {
+    GSR_OK = 0,
+    GSR_ERR_BAD_ARG = -1,       /* null pointer, non-positive size, unsupported option */
+    GSR_ERR_WORKSPACE = -2,     /* workspace smaller than gsr_workspace_bytes() says */
+    GSR_ERR_PAIR_OVERFLOW = -3, /* (gaussian,tile) pairs exceeded max_pairs: frame is incomplete, re-render with more */
+    GSR_ERR_HIP = -4            /* a HIP runtime call failed; see gsr_last_error() */
+} GsrStatus;
+
+/* Constants of rasterize.py:29-38 and the literals buried in the reference's glue. */
+#define GSR_TILE 16                  /* BLOCK_SIZE, rasterize.py:34 */
+#define GSR_GAUSSIAN_SPREAD 3.0f     /* rasterize.py:32 */
+#define GSR_MAX_ALPHA 0.99f          /* MAX_GAUSSIAN_DENSITY, rasterize.py:36 */
+#define GSR_MIN_ALPHA (1.0f / 255.0f)/* rasterize.py:38 */
+#define GSR_CULL_Z 0.2f              /* rasterize.py:377 */
+#define GSR_LOWPASS 0.3f             /* rasterize.py:249-250 */
+#define GSR_EIG_FLOOR 0.1f           /* rasterize.py:172,175 */
+
+/* Camera-independent trained gaussians, exactly the values stored in the INRIA .ply
+ * (rasterize.py:98-106,354-358; utils.py:10-31).  Row-major dense arrays. */
+typedef struct GsrScene {
+    int64_t n;                  /* number of gaussians */
+    const float *means;         /* [n,3]  x,y,z */
+    const float *log_scales;    /* [n,3]  scale_0..2, BEFORE exp (rasterize.py:97) */
+    const float *quats;         /* [n,4]  rot_0..3 = (w,x,y,z), un-normalised (rasterize.py:99-112) */
+    const float *opacity_logit; /* [n]    BEFORE sigmoid (rasterize.py:358) */
+    const float *sh;            /* [n,16,3] sh[i][k][c], k=0 is f_dc (utils.py:21-31) */
+    int32_t sh_degree;          /* 0..3; the reference always evaluates 3 (rasterize.py:368) */
+    int32_t _pad;
+} GsrScene;
+
+/* One view.  Filled by gsr_camera_setup() or by hand.  All matrices are in the reference's
+ * row-vector convention (transposed at rasterize.py:361-362): x_cam = x_w @ w2c[:3,:3] + w2c[3,:3]. */
+typedef struct GsrCamera {
+    float w2c[16];        /* get_world_to_camera_matrix(...).T, rasterize.py:59-77,:361 */
+    float full_proj[16];  /* w2c @ get_projection_matrix(...).T, rasterize.py:123-151,:362-364 */
+    float cam_center[3];  /* inverse(w2c)[3,:3], spherical_harmonics.py:35 */
+    float focal_x, focal_y;     /* focal of the EWA Jacobian = full-res fx,fy / 2 (rasterize.py:216; quirk Q3) */
+    float lim_x, lim_y;         /* fp32(1.3*tan(fov/2)), rasterize.py:210-211 */
+    float tan_fov_x, tan_fov_y; /* rasterize.py:344-345 */
+    int32_t width, height;      /* output size in pixels, rasterize.py:338 */
+} GsrCamera;
+
+typedef struct GsrOptions {
+    int32_t reference_compat; /* 1 (default): reproduce Q1 (column W-1 / row H-1 never drawn, rasterize.py:271-272,
+                                 :415-418) and Q2 (skip if ANY conic entry == 0, :441).  0: draw every pixel. */
+    float early_out_T;        /* 0 (default) = blend every gaussian like the reference (Q5).  >0: a pixel stops
+                                 once its transmittance falls below this (an approximation; INRIA uses 1e-4). */
+    int32_t tile_row_begin;   /* multi-GPU sharding: this call bins+blends tile rows begin, begin+step, ... */
+    int32_t tile_row_step;    /* default 0 / 1 = all rows */
+    int32_t output_layout;    /* 0 (default): image [H,W,3] (= screen.transpose(1,0), rasterize.py:471);
+                                 1: reference `screen` layout [W,H,3] (rasterize.py:437);
+                                 2: compact strip [rows_of_this_shard*16, W, 3] for the framebuffer gather */
+    int32_t no_footprint_cull;/* 0 (default): tile rects / quadrant tests are tightened to the AABB of the region where
+                                 alpha > 1/255 can hold (exact: skipped work contributes nothing).  1: bin the
+                                 reference's full 3-sigma tile rect — only to prove that property in tests. */
+    int32_t _pad[2];
+} GsrOptions;
+
+/* Counters of one frame (device -> host with gsr_read_stats). */
+typedef struct GsrStats {
+    uint32_t n_visible;     /* V: gaussians that survive cull and have a non-empty footprint */
+    uint32_t n_pairs_bbox;  /* D: (gaussian,tile) pairs of the visible gaussians' tile rects (this shard) */
+    uint32_t n_pairs;       /* E: pairs actually sorted and consumed by the blend (after footprint culling) */
+    uint32_t overflow;      /* 1 if D exceeded max_pairs (frame incomplete) */
+    uint32_t max_list_len;  /* longest per-tile list */
+    uint32_t _pad[3];
+} GsrStats;
+
+/* Optional intermediates of gsr_preprocess, one entry per gaussian, any pointer may be NULL.
+ * They are the tensors the reference's helpers return (used by the drop-in helper functions and parity tests). */
+typedef struct GsrDebugOut {
+    float *cov3d;         /* [n,9]  get_covariance_matrix_from_mesh, rasterize.py:89-120 */
+    float *cam_means;     /* [n,3]  project_to_camera_space, rasterize.py:80-86 */
+    float *cov2d;         /* [n,4]  compute_2d_covariance, rasterize.py:201-252 (before the cull zeroing of :388) */
+    float *screen_means;  /* [n,2]  rasterize.py:391 */
+    int64_t *tile_bboxes; /* [n,4]  compute_covering_bbox, rasterize.py:154-198 */
+    float *sigmas;        /* [n,3]  conic (sigma_x, sigma_y, sigma_xy), rasterize.py:404-411 */
+    int64_t *pixel_bboxes;/* [n,4]  rasterize.py:415-419 */
+    float *rgb;           /* [n,3]  sh_to_rgb, spherical_harmonics.py:27-73 */
+    float *opacity;       /* [n]    sigmoid(opacity_logit), rasterize.py:358 */
+} GsrDebugOut;
+
+int gsr_version(void);
+const char *gsr_last_error(void);
+void gsr_default_options(GsrOptions *opts /* [host] */);
+
+/* [host] Camera set-up from COLMAP extrinsics/intrinsics: replaces rasterize.py:336-345 (fov, focals),
+ * :59-77 + :361 (world->camera), :123-151 + :362-364 (projection, full transform) and
+ * spherical_harmonics.py:35 (camera centre).  fx_full/fy_full/cam_width/cam_height are the FULL-RES camera
+ * of cameras.bin (cam_info[1]); width/height the size of the images_{K} frame (rasterize.py:338). */
+int gsr_camera_setup(const double qvec[4], const double tvec[3], double fx_full, double fy_full, int64_t cam_width,
+                     int64_t cam_height, int32_t width, int32_t height, GsrCamera *out /* [host] */);
+
+/* Bytes of scratch one frame needs for n gaussians, a width x height target and room for max_pairs
+ * (gaussian,tile) pairs.  max_pairs is the caller's bound on D; exceeding it is reported, never UB. */
+int gsr_workspace_bytes(int64_t n, int32_t width, int32_t height, int64_t max_pairs, size_t *bytes /* [host] */);
+
+/* Stage 1 — per-gaussian preprocessing, fused: rasterize.py:354-420 (means, cov3D, opacity, SH colour,
+ * camera/clip projection, z<0.2 cull, EWA 2D covariance, NDC->pixel, radius + tile rect, conic, pixel rect). */
+int gsr_preprocess(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
+                   size_t workspace_bytes, const GsrDebugOut *debug /* [host], may be NULL */, void *stream);
+
+/* Stage 2 — depth order (rasterize.py:424-425, ties broken by gaussian index) and 16x16 tile binning:
+ * radix sort of the visible gaussians by depth, pair emission in depth order, stable radix sort by tile,
+ * per-tile [begin,end) ranges.  Needs gsr_preprocess on the same workspace first. */
+int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs, void *workspace,
+                 size_t workspace_bytes, void *stream);
+
+/* Stage 3 — front-to-back compositing of every tile list: rasterize.py:436-446 (driver loop + skip guard)
+ * and :255-305 (rasterize_gaussian).  out_image layout per opts->output_layout; out_final_T [H,W] may be NULL.
+ * n and max_pairs must be the values given to the earlier stages (the library keeps no state; they fix the
+ * workspace layout). */
+int gsr_blend(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs, void *workspace,
+              size_t workspace_bytes, float *out_image, float *out_final_T, void *stream);
+
+/* Stages 1-3 back to back: the whole render call of rasterize.py:354-446. */
+int gsr_render_forward(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,
+                       void *workspace, size_t workspace_bytes, float *out_image, float *out_final_T, void *stream);
+
+/* Copies the frame counters to host memory and waits for the stream.  Returns GSR_ERR_PAIR_OVERFLOW if the
+ * frame overflowed max_pairs. */
+int gsr_read_stats(const void *workspace, size_t workspace_bytes, GsrStats *out /* [host] */, void *stream);
+
+/* Stand-alone helpers behind the reference's helper functions (same maths as inside gsr_preprocess). */
+/* sh_to_rgb, spherical_harmonics.py:27-73 */
+int gsr_sh_to_rgb(int64_t n, const float *means, const float *sh, const float cam_center[3] /* [host] */, int32_t degree,
+                  float *rgb_out, void *stream);
+/* get_covariance_matrix_from_mesh, rasterize.py:89-120: out [n,9] */
+int gsr_cov3d(int64_t n, const float *log_scales, const float *quats, float *cov3d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */

@@ -1,0 +1,73 @@
+"""CPU: the C-ABI library loads and exports every symbol include/gsr.h declares; host-only entry points work."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_golden
+
+
+def _declared():
+    text = open(os.path.join(REPO, "include", "gsr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    from gsr_amd import _lib
+
+    names = _declared()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(_lib.lib, n), f"{n} declared in include/gsr.h but not exported by libgsr.so"
+    assert sorted(_lib.EXPORTS) == names
+    assert _lib.lib.gsr_version() == 100
+
+
+def test_struct_sizes_match_header():
+    from gsr_amd import _lib
+
+    assert C.sizeof(_lib.GsrScene) == 56
+    assert C.sizeof(_lib.GsrCamera) == 4 * (16 + 16 + 3 + 6) + 8
+    assert C.sizeof(_lib.GsrOptions) == 32
+    assert C.sizeof(_lib.GsrStats) == 32
+    assert C.sizeof(_lib.GsrDebugOut) == 72
+
+
+def test_camera_setup_host_path_matches_oracle_and_reference():
+    from gsr_amd import _lib
+    from oracle import cpu_oracle as orc
+
+    g = load_golden("f1_unit.npz")
+    args = (g["qvec"], g["tvec"], float(g["fx_full"]), float(g["fy_full"]), int(g["cam_width"]), int(g["cam_height"]),
+            int(g["width"]), int(g["height"]))
+    cam, ocam = _lib.camera_setup(*args), orc.camera(*args)
+    assert bytes(cam) == bytes(ocam)
+    assert np.array_equal(np.array(cam.w2c, np.float32).reshape(4, 4), g["w2c_T"])
+
+
+def test_workspace_query_and_error_codes():
+    from gsr_amd import _lib
+
+    small = _lib.workspace_bytes(1000, 640, 360, 10_000)
+    big = _lib.workspace_bytes(1_000_000, 1920, 1080, 16_000_000)
+    assert 0 < small < big and big % 256 == 0
+    with pytest.raises(_lib.GsrError) as e:
+        _lib.workspace_bytes(-1, 640, 360, 10)
+    assert e.value.code == _lib.GSR_ERR_BAD_ARG
+    with pytest.raises(_lib.GsrError):
+        _lib.camera_setup([1, 0, 0, 0], [0, 0, 0], -1.0, 1.0, 10, 10, 10, 10)
+    o = _lib.default_options()
+    assert (o.reference_compat, o.early_out_T, o.tile_row_begin, o.tile_row_step, o.output_layout) == (1, 0.0, 0, 1, 0)
+
+
+def test_gpu_entry_points_reject_bad_arguments_without_touching_a_gpu():
+    from gsr_amd import _lib
+
+    sc, cam, o = _lib.GsrScene(), _lib.GsrCamera(), _lib.default_options()
+    sc.n = 10                                                    # null arrays
+    assert _lib.lib.gsr_render_forward(C.byref(sc), C.byref(cam), C.byref(o), 100, None, 0, None, None, None) == _lib.GSR_ERR_BAD_ARG
+    assert b"null" in _lib.lib.gsr_last_error()
+    assert _lib.lib.gsr_blend(0, C.byref(cam), C.byref(o), 0, None, 0, None, None, None) == _lib.GSR_ERR_BAD_ARG

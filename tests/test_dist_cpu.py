@@ -1,0 +1,74 @@
+"""CPU, world_size 2 (and 3) over gloo: the tile-row shard plan, the framebuffer gather and the reassembly
+(gsr_amd/dist.py) — the N>1 data path of bench.py minus the HIP render that fills the strips."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, H, W, q):
+    import sys
+
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gsr_amd import dist as gdist
+
+    g = torch.Generator().manual_seed(1234)
+    frame = torch.rand((H, W, 3), generator=g)                   # same "rendered frame" on every rank
+    plan = gdist.TileRowPlan(H, W, world)
+    fg = gdist.FrameGather(plan, rank, "cpu")
+    own = fg.own_view()
+    assert tuple(own.shape) == plan.strip_shape(rank)
+    own.copy_(plan.split(frame, rank)[: own.shape[0]])           # what libgsr would write (output_layout = 2)
+    out = fg.gather()
+    ok = True
+    if rank == 0:
+        ok = bool(torch.equal(out, frame))
+    else:
+        ok = out is None
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+@pytest.mark.parametrize("world,H,W", [(2, 96, 160), (2, 93, 150), (3, 200, 64)])
+def test_gather_reassembles_the_frame(world, H, W):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, H, W, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(r, True) for r in range(world)]
+
+
+def test_plan_covers_every_tile_row_once():
+    from gsr_amd import dist as gdist
+
+    for H in (16, 17, 93, 1080, 2160):
+        for world in (1, 2, 3, 4, 8):
+            plan = gdist.TileRowPlan(H, 64, world)
+            rows = sorted(r for rs in plan.rows for r in rs)
+            assert rows == list(range((H + 15) // 16))
+            assert max(len(r) for r in plan.rows) - min(len(r) for r in plan.rows) <= 1
+            frame = torch.arange(H * 64 * 3, dtype=torch.float32).view(H, 64, 3)
+            assert torch.equal(plan.assemble([plan.split(frame, r) for r in range(world)]), frame)

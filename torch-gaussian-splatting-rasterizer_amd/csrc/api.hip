@@ -1,0 +1,288 @@
+// api.hip — the extern "C" surface of libgsr.so (include/gsr.h) and its host-side logic.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "gsr_internal.h"
+
+namespace gsr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return GSR_ERR_HIP;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max_pairs, Workspace *ws)
+{
+    char *p = static_cast<char *>(base);
+    size_t off = 0;
+    auto take = [&](size_t bytes) -> void * {
+        void *r = p ? p + off : nullptr;
+        off = align_up(off + bytes, 256);
+        return r;
+    };
+    const size_t nn = (size_t)std::max<int64_t>(n, 1), np = (size_t)std::max<int64_t>(max_pairs, 1);
+    ws->n = n;
+    ws->max_pairs = max_pairs;
+    ws->tiles_x = (width + GSR_TILE - 1) / GSR_TILE;
+    ws->tiles_y = (height + GSR_TILE - 1) / GSR_TILE;
+    ws->hist_blocks = (int)((std::max(nn, np) + SORT_TILE - 1) / SORT_TILE);
+    ws->ctrl = static_cast<FrameCtrl *>(take(sizeof(FrameCtrl)));
+    ws->rec = static_cast<GaussRec *>(take(sizeof(GaussRec) * nn));
+    ws->rect = static_cast<ushort4 *>(take(sizeof(ushort4) * nn));
+    for (int b = 0; b < 2; ++b) ws->key[b] = static_cast<uint32_t *>(take(4 * nn));
+    for (int b = 0; b < 2; ++b) ws->val[b] = static_cast<uint32_t *>(take(4 * nn));
+    ws->blk_sum = static_cast<uint32_t *>(take(4 * ((nn + EMIT_THREADS - 1) / EMIT_THREADS + 1)));
+    ws->hist = static_cast<uint32_t *>(take(4 * 256 * (size_t)ws->hist_blocks));
+    for (int b = 0; b < 2; ++b) ws->pkey[b] = static_cast<uint32_t *>(take(4 * np));
+    for (int b = 0; b < 2; ++b) ws->pval[b] = static_cast<uint32_t *>(take(4 * np));
+    ws->ranges = static_cast<uint2 *>(take(sizeof(uint2) * (size_t)ws->tiles_x * ws->tiles_y));
+    ws->pair_off = nullptr;
+    ws->bytes = off;
+    return off;
+}
+
+static int check_frame(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs, void *workspace,
+                       size_t workspace_bytes, Workspace *ws)
+{
+    if (!cam || !opts || !workspace) { set_error("null camera/options/workspace"); return GSR_ERR_BAD_ARG; }
+    if (n < 0 || n > 0x7FFFFFFF) { set_error("n = %lld out of range", (long long)n); return GSR_ERR_BAD_ARG; }
+    if (cam->width <= 0 || cam->height <= 0 || cam->width > 65535 * GSR_TILE || cam->height > 65535 * GSR_TILE) {
+        set_error("bad frame size %dx%d", cam->width, cam->height); return GSR_ERR_BAD_ARG;
+    }
+    if (max_pairs < 0 || max_pairs > 0xFFFFFFF0ll) { set_error("max_pairs = %lld out of range", (long long)max_pairs); return GSR_ERR_BAD_ARG; }
+    if (opts->tile_row_step < 0 || opts->tile_row_begin < 0 || opts->tile_row_begin >= std::max(opts->tile_row_step, 1)) {
+        set_error("bad tile-row shard %d/%d", opts->tile_row_begin, opts->tile_row_step); return GSR_ERR_BAD_ARG;
+    }
+    if (opts->output_layout < 0 || opts->output_layout > 2) { set_error("bad output_layout %d", opts->output_layout); return GSR_ERR_BAD_ARG; }
+    if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) { set_error("workspace must be 256-byte aligned"); return GSR_ERR_BAD_ARG; }
+    const size_t need = carve_workspace(workspace, n, cam->width, cam->height, max_pairs, ws);
+    if (workspace_bytes < need) {
+        set_error("workspace too small: %zu bytes given, %zu needed", workspace_bytes, need);
+        return GSR_ERR_WORKSPACE;
+    }
+    return GSR_OK;
+}
+
+}  // namespace gsr
+
+using namespace gsr;
+
+extern "C" {
+
+int gsr_version(void) { return GSR_VERSION; }
+
+const char *gsr_last_error(void) { return g_err; }
+
+void gsr_default_options(GsrOptions *o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->reference_compat = 1;
+    o->early_out_T = 0.0f;
+    o->tile_row_begin = 0;
+    o->tile_row_step = 1;
+    o->output_layout = 0;
+}
+
+int gsr_camera_setup(const double qvec[4], const double tvec[3], double fx_full, double fy_full, int64_t cam_width,
+                     int64_t cam_height, int32_t width, int32_t height, GsrCamera *cam)
+{
+    if (!qvec || !tvec || !cam) { set_error("null argument"); return GSR_ERR_BAD_ARG; }
+    if (!(fx_full > 0.0) || !(fy_full > 0.0) || cam_width <= 0 || cam_height <= 0 || width <= 0 || height <= 0) {
+        set_error("bad intrinsics"); return GSR_ERR_BAD_ARG;
+    }
+    const double Z_FAR = 100.0, Z_NEAR = 0.01;  // rasterize.py:29-30
+    // world -> camera: the quaternion formula of rasterize.py:41-56 evaluated in float64 on the COLMAP qvec
+    // (un-normalised, Q8), cast to fp32 (:56), +tvec in the last column (:75), then transposed (:361).
+    const double w = qvec[0], x = qvec[1], y = qvec[2], z = qvec[3];
+    const double R[3][3] = {
+        {1 - 2 * (y * y) - 2 * (z * z), 2 * x * y - 2 * z * w, 2 * x * z + 2 * y * w},
+        {2 * x * y + 2 * z * w, 1 - 2 * (x * x) - 2 * (z * z), 2 * y * z - 2 * x * w},
+        {2 * x * z - 2 * y * w, 2 * y * z + 2 * x * w, 1 - 2 * (x * x) - 2 * (y * y)}};
+    float M[4][4] = {{0}};
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) M[i][j] = (float)R[i][j];
+        M[i][3] = (float)tvec[i];
+    }
+    M[3][3] = 1.0f;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) cam->w2c[4 * i + j] = M[j][i];
+    // field of view from the full-resolution camera, rasterize.py:342-345
+    const double fov_x = 2.0 * std::atan((double)cam_width / (2.0 * fx_full));
+    const double fov_y = 2.0 * std::atan((double)cam_height / (2.0 * fy_full));
+    cam->tan_fov_x = (float)std::tan(fov_x * 0.5);
+    cam->tan_fov_y = (float)std::tan(fov_y * 0.5);
+    cam->lim_x = (float)(1.3 * std::tan(fov_x * 0.5));  // :210
+    cam->lim_y = (float)(1.3 * std::tan(fov_y * 0.5));  // :211
+    cam->focal_x = (float)(fx_full / 2.0);              // :216 (Q3: always full-res / 2)
+    cam->focal_y = (float)(fy_full / 2.0);
+    // perspective matrix, rasterize.py:123-151 (float64 python arithmetic stored into an fp32 tensor)
+    const double thx = std::tan(fov_x / 2), thy = std::tan(fov_y / 2);
+    const double top = thy * Z_NEAR, bottom = -top, right = thx * Z_NEAR, left = -right;
+    float P[4][4] = {{0}};
+    P[0][0] = (float)(2.0 * Z_NEAR / (right - left));
+    P[1][1] = (float)(2.0 * Z_NEAR / (top - bottom));
+    P[0][2] = (float)((right + left) / (right - left));
+    P[1][2] = (float)((top + bottom) / (top - bottom));
+    P[3][2] = 1.0f;
+    P[2][2] = (float)(Z_FAR / (Z_FAR - Z_NEAR));
+    P[2][3] = (float)(-(Z_FAR * Z_NEAR) / (Z_FAR - Z_NEAR));
+    for (int i = 0; i < 4; ++i)  // full = w2c @ P^T in fp32, :364
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0.0f;
+            for (int k = 0; k < 4; ++k) acc = acc + cam->w2c[4 * i + k] * P[j][k];
+            cam->full_proj[4 * i + j] = acc;
+        }
+    // camera centre = inverse(w2c)[3,:3] (spherical_harmonics.py:35) = -t A^-1, A = w2c[:3,:3]; float64, one cast
+    double A[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[i][j] = (double)cam->w2c[4 * i + j];
+    const double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1], c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2],
+                 c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    const double det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
+    if (det == 0.0 || !std::isfinite(det)) { set_error("singular world-to-camera rotation"); return GSR_ERR_BAD_ARG; }
+    const double inv[3][3] = {
+        {c00 / det, (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det, (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det},
+        {c01 / det, (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det, (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det},
+        {c02 / det, (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det, (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det}};
+    for (int j = 0; j < 3; ++j) {
+        double c = 0.0;
+        for (int k = 0; k < 3; ++k) c -= (double)cam->w2c[12 + k] * inv[k][j];
+        cam->cam_center[j] = (float)c;
+    }
+    cam->width = width;
+    cam->height = height;
+    return GSR_OK;
+}
+
+int gsr_workspace_bytes(int64_t n, int32_t width, int32_t height, int64_t max_pairs, size_t *bytes)
+{
+    if (!bytes || n < 0 || width <= 0 || height <= 0 || max_pairs < 0) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
+    Workspace ws;
+    *bytes = carve_workspace(nullptr, n, width, height, max_pairs, &ws);
+    return GSR_OK;
+}
+
+static int check_scene(const GsrScene *sc)
+{
+    if (!sc) { set_error("null scene"); return GSR_ERR_BAD_ARG; }
+    if (sc->n > 0 && (!sc->means || !sc->log_scales || !sc->quats || !sc->opacity_logit || !sc->sh)) {
+        set_error("null scene array"); return GSR_ERR_BAD_ARG;
+    }
+    if (sc->sh_degree < 0 || sc->sh_degree > 3) { set_error("sh_degree %d not in 0..3", sc->sh_degree); return GSR_ERR_BAD_ARG; }
+    if (reinterpret_cast<uintptr_t>(sc->sh) % 16 != 0 || reinterpret_cast<uintptr_t>(sc->quats) % 16 != 0) {
+        set_error("sh and quats must be 16-byte aligned"); return GSR_ERR_BAD_ARG;
+    }
+    return GSR_OK;
+}
+
+int gsr_preprocess(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
+                   size_t workspace_bytes, const GsrDebugOut *debug, void *stream)
+{
+    int rc = check_scene(scene);
+    if (rc) return rc;
+    Workspace ws;
+    // stage 1 does not touch the pair buffers: any max_pairs >= 0 gives the same per-gaussian layout,
+    // so size-check against the smallest one.
+    rc = check_frame(scene->n, cam, opts, 0, workspace, workspace_bytes, &ws);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GSR_HIP(hipMemsetAsync(ws.ctrl, 0, sizeof(FrameCtrl), s));
+    return launch_preprocess(*scene, *cam, *opts, ws, debug, s);
+}
+
+int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs, void *workspace,
+                 size_t workspace_bytes, void *stream)
+{
+    Workspace ws;
+    int rc = check_frame(n, cam, opts, max_pairs, workspace, workspace_bytes, &ws);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int buf = 0;
+    // depth order: 4 x 8-bit passes over the 32 key bits; pass 0 drops culled gaussians and leaves V in ctrl
+    rc = launch_radix_sort(ws.key, ws.val, nullptr, n, 4, true, &ws.ctrl->n_visible, ws, &buf, s);
+    if (rc) return rc;
+    rc = launch_binning(*cam, *opts, ws, buf, s);
+    if (rc) return rc;
+    int pbuf = 0;
+    rc = launch_radix_sort(ws.pkey, ws.pval, &ws.ctrl->n_pairs, max_pairs, tile_sort_passes(ws.tiles_x * ws.tiles_y), false,
+                           nullptr, ws, &pbuf, s);
+    if (rc) return rc;
+    return launch_tile_ranges(ws, pbuf, s);
+}
+
+int gsr_blend(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs, void *workspace,
+              size_t workspace_bytes, float *out_image, float *out_final_T, void *stream)
+{
+    if (!out_image) { set_error("null output image"); return GSR_ERR_BAD_ARG; }
+    Workspace ws;
+    int rc = check_frame(n, cam, opts, max_pairs, workspace, workspace_bytes, &ws);
+    if (rc) return rc;
+    const int pbuf = tile_sort_passes(ws.tiles_x * ws.tiles_y) & 1;  // ping-pong parity of the tile sort
+    return launch_blend(*cam, *opts, ws, max_pairs > 0 ? pbuf : 0, out_image, out_final_T, static_cast<hipStream_t>(stream));
+}
+
+int gsr_render_forward(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,
+                       void *workspace, size_t workspace_bytes, float *out_image, float *out_final_T, void *stream)
+{
+    int rc = check_scene(scene);
+    if (rc) return rc;
+    if (!out_image) { set_error("null output image"); return GSR_ERR_BAD_ARG; }
+    Workspace ws;
+    rc = check_frame(scene->n, cam, opts, max_pairs, workspace, workspace_bytes, &ws);
+    if (rc) return rc;
+    rc = gsr_preprocess(scene, cam, opts, workspace, workspace_bytes, nullptr, stream);
+    if (rc) return rc;
+    rc = gsr_bin_sort(scene->n, cam, opts, max_pairs, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    return gsr_blend(scene->n, cam, opts, max_pairs, workspace, workspace_bytes, out_image, out_final_T, stream);
+}
+
+int gsr_read_stats(const void *workspace, size_t workspace_bytes, GsrStats *out, void *stream)
+{
+    if (!workspace || !out || workspace_bytes < sizeof(FrameCtrl)) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
+    static_assert(sizeof(GsrStats) == 32, "GsrStats is the head of FrameCtrl");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GSR_HIP(hipMemcpyAsync(out, workspace, sizeof(GsrStats), hipMemcpyDeviceToHost, s));
+    GSR_HIP(hipStreamSynchronize(s));
+    if (out->overflow) {
+        set_error("pair overflow: the frame needs %u (gaussian,tile) pairs", out->n_pairs_bbox);
+        return GSR_ERR_PAIR_OVERFLOW;
+    }
+    return GSR_OK;
+}
+
+int gsr_sh_to_rgb(int64_t n, const float *means, const float *sh, const float cam_center[3], int32_t degree, float *rgb_out,
+                  void *stream)
+{
+    if (n < 0 || (n > 0 && (!means || !sh || !rgb_out)) || !cam_center || degree < 0 || degree > 3) {
+        set_error("bad argument"); return GSR_ERR_BAD_ARG;
+    }
+    if (reinterpret_cast<uintptr_t>(sh) % 16 != 0) { set_error("sh must be 16-byte aligned"); return GSR_ERR_BAD_ARG; }
+    return launch_sh_to_rgb(n, means, sh, cam_center, degree, rgb_out, static_cast<hipStream_t>(stream));
+}
+
+int gsr_cov3d(int64_t n, const float *log_scales, const float *quats, float *cov3d_out, void *stream)
+{
+    if (n < 0 || (n > 0 && (!log_scales || !quats || !cov3d_out))) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
+    if (reinterpret_cast<uintptr_t>(quats) % 16 != 0) { set_error("quats must be 16-byte aligned"); return GSR_ERR_BAD_ARG; }
+    return launch_cov3d(n, log_scales, quats, cov3d_out, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// gsr_internal.h — shared declarations of libgsr.so (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/gsr.h"
+
+namespace gsr {
+
+// ---------------------------------------------------------------------------------------------
+// Device control block at the head of the workspace.  Zeroed at the start of every frame.
+// The first 8 words are GsrStats verbatim.
+// ---------------------------------------------------------------------------------------------
+struct FrameCtrl {
+    uint32_t n_visible;     // V  (written by the first depth-sort scatter pass)
+    uint32_t n_pairs_bbox;  // D  (total of the tile-count scan, before clamping)
+    uint32_t n_pairs;       // E  = min(D, max_pairs)
+    uint32_t overflow;
+    uint32_t max_list_len;
+    uint32_t pad[3];
+    uint32_t digit_tot[256]; // per-digit totals of the radix pass in flight
+};
+
+// Per-gaussian record consumed by the blend (48 B, three 16-B loads):
+//   r0 = {mean_x, mean_y, A, B}     power2(dx,dy) = A dx^2 + B dx dy + C dy^2   (log2 domain)
+//   r1 = {C, opacity, red, green}
+//   r2 = {blue, half_extent_x, half_extent_y, unused}   (AABB of the alpha > 1/255 footprint)
+struct alignas(16) GaussRec {
+    float4 r0, r1, r2;
+};
+
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 16;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // keys per workgroup per radix pass
+constexpr int EMIT_THREADS = 256;                     // gaussians per workgroup in count/emit
+constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
+
+struct Workspace {
+    FrameCtrl *ctrl;
+    GaussRec *rec;        // [n]
+    ushort4 *rect;        // [n]   tile rect {tx0, ty0, tx1, ty1} (exclusive upper), after footprint refinement
+    uint32_t *key[2];     // [n]   depth keys (ping-pong)
+    uint32_t *val[2];     // [n]   gaussian ids (ping-pong)
+    uint32_t *pair_off;   // [n]   exclusive pair offsets in depth order
+    uint32_t *blk_sum;    // [ceil(n/EMIT_THREADS)+1]
+    uint32_t *hist;       // [256 * hist_blocks]
+    uint32_t *pkey[2];    // [max_pairs] tile ids
+    uint32_t *pval[2];    // [max_pairs] gaussian ids
+    uint2 *ranges;        // [tiles]
+    int64_t n;
+    int64_t max_pairs;
+    int tiles_x, tiles_y;
+    int hist_blocks;      // row stride of `hist`
+    size_t bytes;
+};
+
+// Carves `base` (may be nullptr to only size).  Returns total bytes.
+size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max_pairs, Workspace *ws);
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+
+#define GSR_HIP(call)                                      \
+    do {                                                   \
+        hipError_t e__ = (call);                           \
+        if (e__ != hipSuccess) return gsr::hip_fail(e__, #call); \
+    } while (0)
+
+// ---- kernels' host launchers (each returns GSR_OK / GSR_ERR_HIP) --------------------------------
+int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws,
+                      const GsrDebugOut *dbg, hipStream_t s);
+int launch_sh_to_rgb(int64_t n, const float *means, const float *sh, const float cc[3], int degree, float *rgb, hipStream_t s);
+int launch_cov3d(int64_t n, const float *log_scales, const float *quats, float *out, hipStream_t s);
+
+// LSD radix sort of (key,val) u32 pairs, 8 bits per pass over bits [0, 8*passes).
+// n_dev: device pointer to the element count (may be nullptr -> n_bound is the count).
+// drop_invalid_first: pass 0 drops keys == KEY_INVALID and stores the survivor count to n_out (device).
+// On return *result_buf (0/1) tells which of key[]/val[] holds the sorted data.
+int launch_radix_sort(uint32_t *const key[2], uint32_t *const val[2], const uint32_t *n_dev, int64_t n_bound, int passes,
+                      bool drop_invalid_first, uint32_t *n_out, const Workspace &ws, int *result_buf, hipStream_t s);
+
+int launch_binning(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int sorted_buf, hipStream_t s);
+int launch_tile_ranges(const Workspace &ws, int pair_buf, hipStream_t s);
+int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int pair_buf, float *out_image,
+                 float *out_T, hipStream_t s);
+
+// which pair buffer holds the tile-sorted pairs, given the tile count (passes parity)
+int tile_sort_passes(int tiles);
+
+// ---- small device helpers -----------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// Exclusive scan across a 256-thread workgroup (4 waves).  `scratch` = 8 uint32 of LDS.  Returns the
+// exclusive prefix of `v`; *total receives the workgroup sum.  Contains two __syncthreads().
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *scratch, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan(v);
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t s = scratch[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+}  // namespace gsr

@@ -1,0 +1,210 @@
+// sort.hip — stable LSD radix sort of (u32 key, u32 value) pairs, 8 bits per pass.
+//
+// Used twice per frame (rasterize.py:424-425 is one torch.sort; tile lists have no reference counterpart):
+//   1. depth order:  keys = IEEE bits of z_cam of every gaussian (KEY_INVALID for culled ones, dropped
+//      by pass 0), values = gaussian id.  Stable from index order => depth ties resolve by index.
+//   2. tile lists:   keys = tile id of every (gaussian,tile) pair emitted IN DEPTH ORDER, values =
+//      gaussian id.  A stable sort by tile therefore leaves every tile's list depth-ordered.
+//
+// Per pass, three launches (no inter-workgroup hand-off inside a launch, so nothing depends on dispatch
+// order or XCD placement):
+//   hist     one workgroup per 4096-key tile: 256-bin digit histogram -> hist[digit][tile]
+//   rowscan  one workgroup per digit: exclusive scan of its row in place, row total -> digit_tot[digit]
+//   scatter  one workgroup per tile: wave-ballot ranking -> tile reordered by digit in LDS -> digit runs
+//            written out contiguously (coalesced), position = digit base + scanned hist + rank in run
+// The element count lives in device memory (n_dev): grids are sized by the host-side bound and
+// surplus workgroups fall through.
+// Roofline: HBM.  Per pass per element: 4 B (hist) + 8 B read + 8 B written.
+#include "gsr_internal.h"
+
+namespace gsr {
+
+__device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t n_bound)
+{
+    if (n_dev == nullptr) return n_bound;
+    const uint32_t n = *n_dev;
+    return n < n_bound ? n : n_bound;
+}
+
+template <bool DROP_INVALID>
+__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t *__restrict__ keys, const uint32_t *n_dev,
+                                                                  uint32_t n_bound, int shift, uint32_t *__restrict__ hist,
+                                                                  int hist_blocks)
+{
+    __shared__ uint32_t h[256];
+    const uint32_t n = load_count(n_dev, n_bound);
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * SORT_TILE;
+    if (base < n) {
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const uint32_t idx = base + r * SORT_THREADS + threadIdx.x;
+            if (idx < n) {
+                const uint32_t k = keys[idx];
+                if (!DROP_INVALID || k != KEY_INVALID) atomicAdd(&h[(k >> shift) & 255u], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * hist_blocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// One workgroup per digit row.  Rows are `hist_blocks` long; only the first `nblk` entries are live.
+__global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t *__restrict__ hist, int hist_blocks, int nblk,
+                                                            uint32_t *__restrict__ digit_tot)
+{
+    __shared__ uint32_t scratch[8];
+    uint32_t *row = hist + (size_t)blockIdx.x * hist_blocks;
+    uint32_t carry = 0;
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i0 = base + threadIdx.x * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (i0 + j < nblk) ? row[i0 + j] : 0u;
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        uint32_t total;
+        uint32_t ex = block_excl_scan_256(mine, scratch, &total) + carry;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i0 + j < nblk) row[i0 + j] = ex;
+            ex += v[j];
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) digit_tot[blockIdx.x] = carry;
+}
+
+template <bool DROP_INVALID>
+__global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint32_t *__restrict__ keys_in,
+                                                                     const uint32_t *__restrict__ vals_in,
+                                                                     uint32_t *__restrict__ keys_out,
+                                                                     uint32_t *__restrict__ vals_out, const uint32_t *n_dev,
+                                                                     uint32_t n_bound, int shift,
+                                                                     const uint32_t *__restrict__ hist, int hist_blocks,
+                                                                     const uint32_t *__restrict__ digit_tot, uint32_t *n_out)
+{
+    __shared__ uint32_t wave_cnt[4][256];   // per-wave digit counts, then per-wave exclusive bases
+    __shared__ uint32_t digit_base[256];    // global position of this tile's run of digit d
+    __shared__ uint32_t tile_start[256];    // start of digit d inside the reordered tile
+    __shared__ uint32_t skey[SORT_TILE];
+    __shared__ uint32_t sval[SORT_TILE];
+    __shared__ uint32_t scratch[8];
+    __shared__ uint32_t s_valid;
+
+    const uint32_t n = load_count(n_dev, n_bound);
+    const uint32_t base = blockIdx.x * SORT_TILE;
+    if (base >= n) return;  // uniform per workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wave_cnt[w][tid] = 0;
+    __syncthreads();
+
+    // wave w owns items [w*1024, (w+1)*1024) of the tile, 16 rounds of 64 consecutive keys:
+    // tile order == (wave, round, lane) order, which is what keeps the sort stable.
+    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const uint32_t idx = base + wave * (64 * SORT_ITEMS) + r * 64 + lane;
+        const bool in = idx < n;
+        key[r] = in ? keys_in[idx] : KEY_INVALID;
+        val[r] = in ? vals_in[idx] : 0u;
+        if (!DROP_INVALID && !in) rank[r] = 0xFFFFFFFFu;  // marks padding when invalid keys are legal data
+    }
+    volatile uint32_t *wc = wave_cnt[wave];
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const uint32_t idx = base + wave * (64 * SORT_ITEMS) + r * 64 + lane;
+        const bool valid = (idx < n) && (!DROP_INVALID || key[r] != KEY_INVALID);
+        const uint32_t d = (key[r] >> shift) & 255u;
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bb = __ballot(bit);
+            m &= bit ? bb : ~bb;
+        }
+        // m = valid lanes of this round that share my digit
+        const uint32_t before = (uint32_t)__popcll(m & lt_mask);
+        uint32_t prior = 0;
+        if (valid) prior = wc[d];
+        if (valid && before == 0) wc[d] = prior + (uint32_t)__popcll(m);  // leader of the digit group
+        rank[r] = valid ? prior + before : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+
+    // digit d = tid: per-wave exclusive bases, tile digit starts, global digit bases
+    {
+        const uint32_t c0 = wave_cnt[0][tid], c1 = wave_cnt[1][tid], c2 = wave_cnt[2][tid], c3 = wave_cnt[3][tid];
+        const uint32_t cnt = c0 + c1 + c2 + c3;
+        uint32_t tile_total, all_total;
+        const uint32_t ts = block_excl_scan_256(cnt, scratch, &tile_total);
+        const uint32_t gs = block_excl_scan_256(digit_tot[tid], scratch, &all_total);
+        wave_cnt[0][tid] = 0; wave_cnt[1][tid] = c0; wave_cnt[2][tid] = c0 + c1; wave_cnt[3][tid] = c0 + c1 + c2;
+        tile_start[tid] = ts;
+        digit_base[tid] = gs + hist[(size_t)tid * hist_blocks + blockIdx.x];
+        if (tid == 0) {
+            s_valid = tile_total;
+            if (n_out != nullptr && blockIdx.x == 0) *n_out = all_total;
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        if (rank[r] != 0xFFFFFFFFu) {
+            const uint32_t d = (key[r] >> shift) & 255u;
+            const uint32_t pos = tile_start[d] + wave_cnt[wave][d] + rank[r];
+            skey[pos] = key[r];
+            sval[pos] = val[r];
+        }
+    }
+    __syncthreads();
+
+    const uint32_t nvalid = s_valid;
+    for (uint32_t i = tid; i < nvalid; i += SORT_THREADS) {
+        const uint32_t k = skey[i];
+        const uint32_t d = (k >> shift) & 255u;
+        const uint32_t gpos = digit_base[d] + (i - tile_start[d]);
+        keys_out[gpos] = k;
+        vals_out[gpos] = sval[i];
+    }
+}
+
+int launch_radix_sort(uint32_t *const key[2], uint32_t *const val[2], const uint32_t *n_dev, int64_t n_bound, int passes,
+                      bool drop_invalid_first, uint32_t *n_out, const Workspace &ws, int *result_buf, hipStream_t s)
+{
+    int cur = 0;
+    *result_buf = 0;
+    if (n_bound <= 0 || passes <= 0) return GSR_OK;
+    const int nblk = (int)((n_bound + SORT_TILE - 1) / SORT_TILE);
+    if (nblk > ws.hist_blocks) { set_error("radix sort: %d tiles exceed the histogram stride %d", nblk, ws.hist_blocks); return GSR_ERR_WORKSPACE; }
+    const uint32_t *cnt_dev = n_dev;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * p;
+        const bool drop = drop_invalid_first && p == 0;
+        uint32_t *dt = ws.ctrl->digit_tot;
+        if (drop) {
+            hipLaunchKernelGGL(radix_hist_kernel<true>, dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], cnt_dev, (uint32_t)n_bound,
+                               shift, ws.hist, ws.hist_blocks);
+            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, s, ws.hist, ws.hist_blocks, nblk, dt);
+            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], val[cur], key[cur ^ 1],
+                               val[cur ^ 1], cnt_dev, (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks, dt, n_out);
+            if (n_out) cnt_dev = n_out;  // later passes only see the survivors
+        } else {
+            hipLaunchKernelGGL(radix_hist_kernel<false>, dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], cnt_dev, (uint32_t)n_bound,
+                               shift, ws.hist, ws.hist_blocks);
+            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, s, ws.hist, ws.hist_blocks, nblk, dt);
+            hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], val[cur], key[cur ^ 1],
+                               val[cur ^ 1], cnt_dev, (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks, dt, (uint32_t *)nullptr);
+        }
+        GSR_HIP(hipGetLastError());
+        cur ^= 1;
+    }
+    *result_buf = cur;
+    return GSR_OK;
+}
+
+}  // namespace gsr

@@ -1,0 +1,100 @@
+"""Tile-row sharding of one frame over the GPUs of a node + the framebuffer gather.
+
+The reference has no distributed code.  A frame shards naturally by 16x16 tile rows: every pixel depends only
+on the gaussians binned to its tile, so rank r bins and blends tile rows r, r+G, r+2G, ... (interleaved, for load
+balance) into a compact strip [rows_r*16, W, 3], and ONE collective — a gather to rank 0 (RCCL over xGMI on the
+GPU box: each peer->root transfer rides its own link) — exchanges the strips.  Per-pixel blend order does not
+depend on the sharding, so the assembled frame is bit-identical to the single-GPU frame.
+
+Everything here works on any `torch.distributed` backend and device (gloo/CPU in the tests, nccl(=RCCL)/GPU in
+bench.py); the strips themselves come from `Rasterizer.enqueue(..., output_layout=2)`.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+TILE = 16
+
+
+class TileRowPlan:
+    """Which tile rows each rank owns, and where its strip rows land in the frame."""
+
+    def __init__(self, height: int, width: int, world: int):
+        if world < 1:
+            raise ValueError("world must be >= 1")
+        self.height, self.width, self.world = int(height), int(width), int(world)
+        self.tiles_y = (self.height + TILE - 1) // TILE
+        self.rows = [list(range(r, self.tiles_y, self.world)) for r in range(self.world)]
+        self.max_rows = max(1, max(len(x) for x in self.rows))
+
+    def strip_shape(self, rank: int):
+        """Shape of rank's compact strip as libgsr writes it (output_layout = 2)."""
+        return (len(self.rows[rank]) * TILE, self.width, 3)
+
+    def padded_shape(self):
+        """Common shape used on the wire (equal-size gather)."""
+        return (self.max_rows * TILE, self.width, 3)
+
+    def shard_options(self, rank: int):
+        return dict(tile_row_begin=rank, tile_row_step=self.world, output_layout=2)
+
+    def assemble(self, strips: List[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """strips[r]: padded strip of rank r -> frame [H,W,3]."""
+        ref = strips[0]
+        padded_h = self.tiles_y * TILE
+        if out is None:
+            out = torch.empty((self.height, self.width, 3), dtype=ref.dtype, device=ref.device)
+        if padded_h == self.height:
+            grid = out.view(self.tiles_y, TILE, self.width, 3)
+            for r, s in enumerate(strips):
+                k = len(self.rows[r])
+                if k:
+                    grid[r::self.world] = s[: k * TILE].view(k, TILE, self.width, 3)
+            return out
+        full = torch.empty((padded_h, self.width, 3), dtype=ref.dtype, device=ref.device)
+        grid = full.view(self.tiles_y, TILE, self.width, 3)
+        for r, s in enumerate(strips):
+            k = len(self.rows[r])
+            if k:
+                grid[r::self.world] = s[: k * TILE].view(k, TILE, self.width, 3)
+        out.copy_(full[: self.height])
+        return out
+
+    def split(self, frame: torch.Tensor, rank: int) -> torch.Tensor:
+        """Inverse of assemble for one rank (tests): the padded strip rank would produce from `frame`."""
+        padded_h = self.tiles_y * TILE
+        full = frame.new_zeros((padded_h, self.width, 3))
+        full[: self.height] = frame
+        strip = frame.new_zeros(self.padded_shape())
+        k = len(self.rows[rank])
+        if k:
+            strip[: k * TILE] = full.view(self.tiles_y, TILE, self.width, 3)[rank::self.world].reshape(k * TILE, self.width, 3)
+        return strip
+
+
+class FrameGather:
+    """Pre-allocated equal-size gather of the strips to rank 0."""
+
+    def __init__(self, plan: TileRowPlan, rank: int, device, dtype=torch.float32, group=None):
+        self.plan, self.rank, self.group = plan, rank, group
+        self.strip = torch.zeros(plan.padded_shape(), dtype=dtype, device=device)
+        self.recv = ([torch.zeros(plan.padded_shape(), dtype=dtype, device=device) for _ in range(plan.world)]
+                     if rank == 0 and plan.world > 1 else None)
+        self.frame = torch.zeros((plan.height, plan.width, 3), dtype=dtype, device=device) if rank == 0 else None
+
+    def own_view(self) -> torch.Tensor:
+        """The leading rows of the wire buffer that libgsr writes this rank's strip into."""
+        k = len(self.plan.rows[self.rank])
+        return self.strip[: k * TILE]
+
+    def gather(self) -> Optional[torch.Tensor]:
+        """Collective: every rank calls it after its strip is complete (stream-ordered). Rank 0 gets the frame."""
+        if self.plan.world == 1:
+            return self.plan.assemble([self.strip], self.frame)
+        dist.gather(self.strip, self.recv if self.rank == 0 else None, dst=0, group=self.group)
+        if self.rank != 0:
+            return None
+        return self.plan.assemble(self.recv, self.frame)

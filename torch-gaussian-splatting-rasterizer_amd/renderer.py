@@ -1,0 +1,195 @@
+"""Host side of the render call: device-resident scene, camera block, workspace, frame launch.
+
+This is the function the reference never had — its render call is the body of
+`run_rasterization` (reference rasterize.py:347-446) and returns nothing; `Rasterizer.render`
+returns the frame.  PyTorch only provides device memory and the stream; all per-gaussian and
+per-pixel work happens in libgsr.so through the C ABI (include/gsr.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Mapping, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GsrCamera, GsrDebugOut, GsrOptions, GsrScene, GsrStats, check, lib
+from .utils import pack_gaussians
+
+TILE = 16
+
+
+def _require_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU: libgsr has no CPU path")
+
+
+def _stream_ptr(device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+class GaussianScene:
+    """Camera-independent trained gaussians, resident in HBM in the layout of GsrScene."""
+
+    FIELDS = ("means", "log_scales", "quats", "opacity_logit", "sh")
+
+    def __init__(self, arrays: Mapping[str, torch.Tensor], sh_degree: int = 3):
+        self.t: Dict[str, torch.Tensor] = {}
+        for k in self.FIELDS:
+            v = arrays[k]
+            _require_cuda(v, k)
+            self.t[k] = v.contiguous().float()
+        self.n = int(self.t["means"].shape[0])
+        self.device = self.t["means"].device
+        self.sh_degree = int(sh_degree)
+        shapes = {"means": (self.n, 3), "log_scales": (self.n, 3), "quats": (self.n, 4), "opacity_logit": (self.n,),
+                  "sh": (self.n, 16, 3)}
+        for k, shp in shapes.items():
+            if tuple(self.t[k].shape) != shp:
+                raise ValueError(f"{k}: expected shape {shp}, got {tuple(self.t[k].shape)}")
+
+    @classmethod
+    def from_columns(cls, columns, device="cuda", sh_degree: int = 3) -> "GaussianScene":
+        """`columns`: ply element / dict of float32 columns named as in the INRIA .ply."""
+        packed = pack_gaussians(columns)
+        return cls({k: torch.from_numpy(v).to(device) for k, v in packed.items()}, sh_degree)
+
+    @classmethod
+    def from_packed(cls, packed: Mapping[str, np.ndarray], device="cuda", sh_degree: int = 3) -> "GaussianScene":
+        return cls({k: torch.from_numpy(np.ascontiguousarray(packed[k], np.float32)).to(device) for k in cls.FIELDS}, sh_degree)
+
+    @classmethod
+    def from_ply(cls, path: str, device="cuda", sh_degree: int = 3) -> "GaussianScene":
+        from .ply import PlyData
+
+        return cls.from_columns(PlyData.read(path), device, sh_degree)
+
+    def c_struct(self) -> GsrScene:
+        s = GsrScene()
+        s.n = self.n
+        for k in self.FIELDS:
+            setattr(s, k, self.t[k].data_ptr())
+        s.sh_degree = self.sh_degree
+        return s
+
+
+def make_camera(qvec, tvec, fx_full: float, fy_full: float, cam_width: int, cam_height: int, width: int, height: int) -> GsrCamera:
+    """COLMAP pose + full-res intrinsics + frame size -> GsrCamera (reference rasterize.py:336-345,:361-364)."""
+    return _lib.camera_setup(qvec, tvec, fx_full, fy_full, cam_width, cam_height, width, height)
+
+
+def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_row_begin: int = 0, tile_row_step: int = 1,
+                 output_layout: int = 0, no_footprint_cull: bool = False) -> GsrOptions:
+    o = _lib.default_options()
+    o.reference_compat = 1 if reference_compat else 0
+    o.early_out_T = float(early_out_T)
+    o.tile_row_begin = int(tile_row_begin)
+    o.tile_row_step = int(tile_row_step)
+    o.output_layout = int(output_layout)
+    o.no_footprint_cull = 1 if no_footprint_cull else 0
+    return o
+
+
+def shard_rows(height: int, begin: int, step: int) -> int:
+    tiles_y = (height + TILE - 1) // TILE
+    return len(range(begin, tiles_y, max(step, 1)))
+
+
+class Rasterizer:
+    """Owns the scratch workspace for one scene and renders frames of it."""
+
+    def __init__(self, scene: GaussianScene, max_pairs: Optional[int] = None):
+        self.scene = scene
+        self.max_pairs = int(max_pairs) if max_pairs else max(1 << 20, 8 * scene.n)
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_key = None
+        self.last_stats: Optional[Dict[str, int]] = None
+
+    # -- workspace ------------------------------------------------------------------------------
+    def _workspace(self, width: int, height: int) -> torch.Tensor:
+        key = (self.scene.n, width, height, self.max_pairs)
+        if self._ws is None or self._ws_key != key:
+            nbytes = _lib.workspace_bytes(self.scene.n, width, height, self.max_pairs)
+            self._ws = None  # free the old one first
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.scene.device)
+            assert self._ws.data_ptr() % 256 == 0
+            self._ws_key = key
+        return self._ws
+
+    def _out_shape(self, cam: GsrCamera, opts: GsrOptions):
+        if opts.output_layout == 0:
+            return (cam.height, cam.width, 3), (cam.height, cam.width)
+        if opts.output_layout == 1:
+            return (cam.width, cam.height, 3), (cam.width, cam.height)
+        rows = shard_rows(cam.height, opts.tile_row_begin, opts.tile_row_step) * TILE
+        return (rows, cam.width, 3), (rows, cam.width)
+
+    # -- one frame ------------------------------------------------------------------------------
+    def enqueue(self, cam: GsrCamera, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None,
+                final_T: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Enqueue one frame on the current stream; no host synchronisation, no overflow check."""
+        opts = opts or make_options()
+        ws = self._workspace(cam.width, cam.height)
+        shape, _ = self._out_shape(cam, opts)
+        if out is None:
+            # strips may include rows below the frame's last pixel row: keep them defined
+            out = torch.zeros(shape, dtype=torch.float32, device=self.scene.device) if opts.output_layout == 2 else \
+                torch.empty(shape, dtype=torch.float32, device=self.scene.device)
+        elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or not out.is_cuda:
+            raise ValueError(f"out must be a contiguous float32 CUDA tensor of shape {shape}")
+        sc = self.scene.c_struct()
+        check(lib.gsr_render_forward(C.byref(sc), C.byref(cam), C.byref(opts), self.max_pairs, ws.data_ptr(), ws.numel(),
+                                     out.data_ptr(), final_T.data_ptr() if final_T is not None else None,
+                                     _stream_ptr(self.scene.device)))
+        return out
+
+    def stats(self) -> Dict[str, int]:
+        """Counters of the last enqueued frame (synchronises the stream).  Raises GsrPairOverflow on overflow."""
+        st = GsrStats()
+        rc = lib.gsr_read_stats(self._ws.data_ptr(), self._ws.numel(), C.byref(st), _stream_ptr(self.scene.device))
+        self.last_stats = st.as_dict()
+        check(rc)
+        return self.last_stats
+
+    def render(self, cam: GsrCamera, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None,
+               return_T: bool = False):
+        """Render one frame and verify it is complete; grows the pair buffer and retries on overflow."""
+        opts = opts or make_options()
+        while True:
+            final_T = None
+            if return_T:
+                _, tshape = self._out_shape(cam, opts)
+                final_T = torch.ones(tshape, dtype=torch.float32, device=self.scene.device)
+            img = self.enqueue(cam, opts, out, final_T)
+            try:
+                self.stats()
+            except _lib.GsrPairOverflow:
+                need = int(self.last_stats["n_pairs_bbox"])
+                if need >= 0xFFFFFFF0:
+                    raise
+                self.max_pairs = int(min(0xFFFFFFF0, need + need // 8 + 1024))
+                continue
+            return (img, final_T) if return_T else img
+
+    # -- stage-by-stage (tests, helper functions) -------------------------------------------------
+    def preprocess_debug(self, cam: GsrCamera, opts: Optional[GsrOptions] = None) -> Dict[str, torch.Tensor]:
+        """Run stage 1 alone and return every per-gaussian intermediate the reference's helpers produce."""
+        opts = opts or make_options()
+        n, dev = self.scene.n, self.scene.device
+        f32, i64 = torch.float32, torch.int64
+        out = {
+            "cov3d": torch.empty((n, 3, 3), dtype=f32, device=dev), "cam_means": torch.empty((n, 3), dtype=f32, device=dev),
+            "cov2d": torch.empty((n, 2, 2), dtype=f32, device=dev), "screen_means": torch.empty((n, 2), dtype=f32, device=dev),
+            "tile_bboxes": torch.empty((n, 4), dtype=i64, device=dev), "sigmas": torch.empty((n, 3), dtype=f32, device=dev),
+            "pixel_bboxes": torch.empty((n, 4), dtype=i64, device=dev), "rgb": torch.empty((n, 3), dtype=f32, device=dev),
+            "opacity": torch.empty((n,), dtype=f32, device=dev),
+        }
+        dbg = GsrDebugOut()
+        for k, v in out.items():
+            setattr(dbg, k, v.data_ptr())
+        ws = self._workspace(cam.width, cam.height)
+        sc = self.scene.c_struct()
+        check(lib.gsr_preprocess(C.byref(sc), C.byref(cam), C.byref(opts), ws.data_ptr(), ws.numel(), C.byref(dbg),
+                                 _stream_ptr(dev)))
+        return out
