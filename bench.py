@@ -41,6 +41,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3
 
 
+def host_threads() -> int:
+    """CPU threads for the host-side legs: the reference's rule cpu_count()-1 (rasterize.py:323), applied to the
+    CPUs this process may actually use, capped at the 16-CPU share a 1-GPU box is allotted."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 2
+    share = int(os.environ.get("GSR_CPU_SHARE", "16"))
+    return max(1, min(avail, share) - 1)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,7 +124,8 @@ def main():
             R.enqueue(cam, opts, out=strip_view)
             return fg.gather()
 
-    # size the pair buffer once (grows on overflow), outside the timed region
+    # size the pair buffer to this view once (grows on overflow), outside the timed region
+    R.fit_pairs(cam, opts)
     R.render(cam, opts, out=strip_view)
     shard_stats = dict(R.last_stats)
     for _ in range(args.warmup):
@@ -192,8 +204,11 @@ def main():
                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                               "algorithmic_bytes_per_launch": blend_bytes, "avg_kernel_ms": stage[2],
                               "note": "blend is VALU/exp-bound in exact mode (SURVEY.md §7 hard part 1); see valu_frac"}
-        # honesty figure: pixel evaluations actually issued are not counted by the kernel; bound from E*256
-        result["roofline"]["valu_upper_bound_frac"] = (E * 256.0 * 24.0) / (stage[2] * 1e-3) / (FP32_PEAK_TFLOPS * 1e12)
+        # honesty figure: pixel evaluations actually issued = 64 per evaluated (quadrant, entry);
+        # ~22 fp32 VALU ops each (2 sub, 5 quadratic, exp2 (counted 4), mul, min, 2 cmp, select, 6 blend)
+        evals = 64.0 * st["wave_entries"]
+        result["roofline"]["pixel_evaluations"] = evals
+        result["roofline"]["valu_frac_of_fp32_peak"] = evals * 22.0 / (stage[2] * 1e-3) / (FP32_PEAK_TFLOPS * 1e12 / 2.0)
         result["stage_ms"] = {"preprocess": stage[0], "bin_sort": stage[1], "blend": stage[2]}
         result["stage_hbm_gbs"] = {"preprocess": pre_bytes / (stage[0] * 1e-3) / 1e9}
         result["stats"] = st
@@ -204,7 +219,7 @@ def main():
             from oracle import cpu_oracle as orc
 
             ocam = orc.camera(*cam_args)
-            threads = max(1, (os.cpu_count() or 2) - 1)
+            threads = host_threads()
             t1 = time.perf_counter()
             pre = orc.preprocess(packed, ocam)
             order = orc.depth_order(pre["cam_means"])
@@ -223,15 +238,16 @@ def main():
         if not args.no_cpu_baseline:
             from oracle import torch_loop
 
-            cores = max(1, (os.cpu_count() or 2) - 1)
+            cores = host_threads()
             torch.set_num_threads(cores)  # the reference sets cpu_count()-1 (rasterize.py:323)
             s = torch_loop.timed_sample(pre, order, W, H, budget_s=args.cpu_budget_s)
             result["cpu_baseline"] = {
                 "value": 1.0 / s["extrapolated_frame_s"], "unit": "frames/s", "cores": cores, "kind": "port",
-                "sample": (f"reference per-gaussian torch loop (oracle/torch_loop.py), {s['sampled']} of {s['total_iterations']} "
-                           f"depth-ordered gaussians (uniform stride) in {s['seconds']:.1f} s: {s['drawn']} drawn at "
-                           f"{1e3 * s['s_per_drawn']:.3f} ms, skipped at {1e6 * s['s_per_skipped']:.1f} us; frame time "
-                           f"extrapolated = {s['extrapolated_frame_s']:.0f} s (excludes the vectorised preprocessing)"),
+                "sample": (f"reference per-gaussian torch loop (oracle/torch_loop.py): uniform random sample of {s['sampled']} of the "
+                           f"frame's {s['total_iterations']} loop iterations, {s['seconds']:.1f} s; {s['drawn']} drawn at "
+                           f"{1e3 * s['s_per_drawn']:.3f} ms each, skipped at {1e6 * s['s_per_skipped']:.1f} us each; frame = "
+                           f"{s['total_drawn']} drawn + rest skipped, extrapolated {s['extrapolated_frame_s']:.0f} s "
+                           f"(excludes the vectorised preprocessing)"),
             }
 
     if rank == 0:

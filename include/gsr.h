@@ -90,7 +90,8 @@ typedef struct GsrStats {
     uint32_t n_pairs;       /* E: pairs actually sorted and consumed by the blend (after footprint culling) */
     uint32_t overflow;      /* 1 if D exceeded max_pairs (frame incomplete) */
     uint32_t max_list_len;  /* longest per-tile list */
-    uint32_t _pad[3];
+    uint32_t _pad;
+    uint64_t wave_entries;  /* (8x8 quadrant, entry) pairs the blend actually evaluated: 64 pixel evaluations each */
 } GsrStats;
 
 /* Optional intermediates of gsr_preprocess, one entry per gaussian, any pointer may be NULL.

@@ -81,7 +81,8 @@ class GsrStats(C.Structure):
         ("n_pairs", C.c_uint32),
         ("overflow", C.c_uint32),
         ("max_list_len", C.c_uint32),
-        ("_pad", C.c_uint32 * 3),
+        ("_pad", C.c_uint32),
+        ("wave_entries", C.c_uint64),
     ]
 
     def as_dict(self):

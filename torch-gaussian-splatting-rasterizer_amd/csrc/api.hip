@@ -52,6 +52,7 @@ size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max
     for (int b = 0; b < 2; ++b) ws->pkey[b] = static_cast<uint32_t *>(take(4 * np));
     for (int b = 0; b < 2; ++b) ws->pval[b] = static_cast<uint32_t *>(take(4 * np));
     ws->ranges = static_cast<uint2 *>(take(sizeof(uint2) * (size_t)ws->tiles_x * ws->tiles_y));
+    ws->tile_order = static_cast<int *>(take(sizeof(int) * 8 * (size_t)((ws->tiles_y + 7) / 8) * ws->tiles_x));
     ws->pair_off = nullptr;
     ws->bytes = off;
     return off;
@@ -221,8 +222,9 @@ int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_
     rc = launch_binning(*cam, *opts, ws, buf, s);
     if (rc) return rc;
     int pbuf = 0;
-    rc = launch_radix_sort(ws.pkey, ws.pval, &ws.ctrl->n_pairs, max_pairs, tile_sort_passes(ws.tiles_x * ws.tiles_y), false,
-                           nullptr, ws, &pbuf, s);
+    // tile lists: stable sort by tile id; pass 0 drops the pairs the emit kernel culled and leaves E in ctrl
+    rc = launch_radix_sort(ws.pkey, ws.pval, &ws.ctrl->n_slots, max_pairs, tile_sort_passes(ws.tiles_x * ws.tiles_y), true,
+                           &ws.ctrl->n_pairs, ws, &pbuf, s);
     if (rc) return rc;
     return launch_tile_ranges(ws, pbuf, s);
 }

@@ -8,12 +8,15 @@
 //           (tile rows begin, begin+step, ...) -> per-workgroup sums
 //   scan    one workgroup: exclusive scan of the workgroup sums; D, overflow flag, E = min(D, max_pairs)
 //   emit    recount + in-workgroup scan -> pair offsets; small rects are written by their own lane,
-//           rects above 32 tiles by the whole wave (the tile count is heavy-tailed: median 4, max thousands)
+//           rects above 32 tiles by the whole wave (the tile count is heavy-tailed: median 4, max thousands).
+//           A tile the gaussian's alpha > 1/255 footprint cannot reach (footprint.h; rect corners of oblique
+//           ellipses) gets KEY_INVALID and is dropped by pass 0 of the tile sort.
 //   ranges  boundaries of equal tile ids in the tile-sorted pair array -> ranges[tile] = [begin, end)
 // Roofline: HBM.  Bytes: 12 B per sorted gaussian (id + rect) + 8 B per pair written; ranges reads 4 B per pair.
 #include <cstring>
 #include <algorithm>
 #include "gsr_internal.h"
+#include "footprint.h"
 
 namespace gsr {
 
@@ -99,12 +102,13 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(uint32_t *__restrict__ 
         const unsigned long long D = grand;
         ctrl->n_pairs_bbox = D > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)D;
         ctrl->overflow = D > (unsigned long long)max_pairs ? 1u : 0u;
-        ctrl->n_pairs = D > (unsigned long long)max_pairs ? max_pairs : (uint32_t)D;
+        ctrl->n_slots = D > (unsigned long long)max_pairs ? max_pairs : (uint32_t)D;
     }
 }
 
 __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t *__restrict__ sorted_ids, const FrameCtrl *ctrl,
                                                                  const ushort4 *__restrict__ rect, Shard sh, int tiles_x,
+                                                                 const GaussRec *__restrict__ rec,
                                                                  const uint32_t *__restrict__ blk_off, uint32_t max_pairs,
                                                                  uint32_t *__restrict__ pkey, uint32_t *__restrict__ pval)
 {
@@ -115,10 +119,12 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
     uint32_t cnt = 0, g = 0;
     int first = 0;
     ushort4 rc = make_ushort4(0, 0, 0, 0);
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
     if (r < n) {
         g = sorted_ids[r];
         rc = rect[g];
         cnt = tiles_of(rc, sh, &first);
+        if (cnt > 0) { q0 = rec[g].q0; q1 = rec[g].q1; }
     }
     uint32_t total;
     const uint32_t off = blk_off[blockIdx.x] + block_excl_scan_256(cnt, scratch, &total);
@@ -133,11 +139,16 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
         big &= big - 1;
         const uint32_t b_cnt = __shfl(cnt, src, 64), b_off = __shfl(off, src, 64), b_g = __shfl(g, src, 64);
         const int b_w = __shfl(width, src, 64), b_x0 = __shfl((int)rc.x, src, 64), b_first = __shfl(first, src, 64);
+        const float4 b_q0 = make_float4(__shfl(q0.x, src, 64), __shfl(q0.y, src, 64), __shfl(q0.z, src, 64), __shfl(q0.w, src, 64));
+        const float4 b_q1 = make_float4(__shfl(q1.x, src, 64), __shfl(q1.y, src, 64), __shfl(q1.z, src, 64), __shfl(q1.w, src, 64));
         for (uint32_t k = lane; k < b_cnt; k += 64) {
             const uint32_t row = k / (uint32_t)b_w, col = k - row * (uint32_t)b_w;
             const uint32_t o = b_off + k;
             if (o < max_pairs) {
-                pkey[o] = (uint32_t)(b_first + (int)row * sh.step) * (uint32_t)tiles_x + (uint32_t)(b_x0 + (int)col);
+                const int tyy = b_first + (int)row * sh.step, txx = b_x0 + (int)col;
+                const bool hit = footprint_hits_rect(b_q0, b_q1, (float)(txx * 16), (float)(txx * 16 + 15), (float)(tyy * 16),
+                                                     (float)(tyy * 16 + 15));
+                pkey[o] = hit ? (uint32_t)tyy * (uint32_t)tiles_x + (uint32_t)txx : KEY_INVALID;
                 pval[o] = b_g;
             }
         }
@@ -149,7 +160,9 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
         for (; ty < rc.w; ty += sh.step) {
             for (int tx = rc.x; tx < rc.z; ++tx, ++o) {
                 if (o < max_pairs) {
-                    pkey[o] = (uint32_t)ty * (uint32_t)tiles_x + (uint32_t)tx;
+                    const bool hit = footprint_hits_rect(q0, q1, (float)(tx * 16), (float)(tx * 16 + 15),
+                                                                     (float)(ty * 16), (float)(ty * 16 + 15));
+                    pkey[o] = hit ? (uint32_t)ty * (uint32_t)tiles_x + (uint32_t)tx : KEY_INVALID;
                     pval[o] = g;
                 }
             }
@@ -199,8 +212,8 @@ int launch_binning(const GsrCamera &cam, const GsrOptions &opts, const Workspace
     const uint32_t cap = (uint32_t)ws.max_pairs;
     hipLaunchKernelGGL(pair_count_kernel, dim3(nblk), dim3(EMIT_THREADS), 0, s, ids, ws.ctrl, ws.rect, sh, ws.blk_sum);
     hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, ws.blk_sum, nblk, ws.ctrl, cap);
-    hipLaunchKernelGGL(pair_emit_kernel, dim3(nblk), dim3(EMIT_THREADS), 0, s, ids, ws.ctrl, ws.rect, sh, ws.tiles_x, ws.blk_sum,
-                       cap, ws.pkey[0], ws.pval[0]);
+    hipLaunchKernelGGL(pair_emit_kernel, dim3(nblk), dim3(EMIT_THREADS), 0, s, ids, ws.ctrl, ws.rect, sh, ws.tiles_x, ws.rec,
+                       ws.blk_sum, cap, ws.pkey[0], ws.pval[0]);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

@@ -7,8 +7,9 @@
 // Per tile list (depth-ordered by the two radix sorts):
 //   - 256 entries at a time are staged in LDS: each thread gathers one 48-B record (3 x 16-B loads)
 //     addressed by the pair value, so HBM/L2 sees 16-B vector loads and the list itself is read coalesced;
-//   - each wave tests, 64 entries per instruction, whether the entry's alpha > 1/255 footprint AABB
-//     touches its quadrant, and walks only the surviving bits of the ballot (scalar loop, no divergence);
+//   - footprint_hits_rect (footprint.h) decides, 64 entries per instruction, whether an entry can touch this
+//     wave's quadrant; the wave walks only the surviving bits of the ballot (scalar loop, no divergence),
+//     two survivors per trip so the second one's LDS broadcast reads overlap the first one's arithmetic;
 //   - per pixel the reference's arithmetic: power (log2 domain, coefficients pre-scaled in preprocess),
 //     alpha = min(opacity * 2^power, 0.99), contribute iff alpha > 1/255 and power <= 0 (:285-291),
 //     C += alpha * T * rgb, T *= 1 - alpha (:295-303);
@@ -16,10 +17,16 @@
 //     stops (wave ballot); the workgroup stops fetching once all four waves have.
 // No early termination by default: the reference blends every gaussian (Q5).
 //
+// Launch order: list lengths are heavy-tailed (longest ~3.5x the mean) and a frame is only ~4 rounds of
+// resident workgroups, so tiles are launched longest-first (tile_order_kernel: per XCD group, bucketed by
+// length).  XCD k (workgroups b with b % 8 == k) takes the tile rows k, k+8, ...: x-neighbours, which share
+// most of their gaussians, hit the same L2, and heavy image regions are spread over all XCDs.
+//
 // Roofline: algorithmic bytes = 40 per consumed entry (4 id + 36 record) + 12 per pixel
 // + 8 per tile range.  At ~20 VALU issues per (pixel, entry) evaluation the kernel is VALU/exp bound,
 // not HBM bound; both fractions are reported by bench.py.
 #include "gsr_internal.h"
+#include "footprint.h"
 
 namespace gsr {
 
@@ -29,6 +36,8 @@ struct BlendArgs {
     const GaussRec *rec;
     float *out;
     float *out_T;
+    FrameCtrl *ctrl;
+    const int *order;     // tile launch order (tile_order_kernel), -1 = empty slot
     int W, H;
     int xlim, ylim;       // pixels x < xlim, y < ylim are drawn (W-1/H-1 in reference_compat: Q1)
     int tiles_x;
@@ -37,6 +46,63 @@ struct BlendArgs {
     float early_T;
 };
 
+// one (pixel, entry) evaluation; g = {mean_x, mean_y}, c = {A, B, C, -}, o = {log2(opacity), r, g, b}.
+// ~16 VALU issues: the kernel is VALU-bound (tools/valu_microbench.hip prices them), so every one counts:
+//   - log2(opacity) rides in the quadratic's constant term: alpha = 2^p with p = power + L, and the reference's
+//     `power <= 0` becomes p <= L;
+//   - T*(1-alpha) is evaluated as T - alpha*T, reusing the product the colour update needs.
+__device__ __forceinline__ void blend_one(const float2 g, const float4 c, const float4 o, float fpx, float fpy, float &T,
+                                          float &Cr, float &Cg, float &Cb)
+{
+    const float dx = g.x - fpx, dy = g.y - fpy;
+    const float p = fmaf(dx, fmaf(c.y, dy, c.x * dx), fmaf(c.z * dy, dy, o.x));  // log2 domain, opacity folded in
+    float alpha = fminf(__builtin_amdgcn_exp2f(p), GSR_MAX_ALPHA);
+    const bool valid = (alpha > GSR_MIN_ALPHA) & (p <= o.x);
+    alpha = valid ? alpha : 0.0f;
+    const float w = alpha * T;
+    Cr = fmaf(w, o.y, Cr);
+    Cg = fmaf(w, o.z, Cg);
+    Cb = fmaf(w, o.w, Cb);
+    T = T - w;
+}
+
+// Tile launch order.  Group g = tile rows g, g+8, ... of the shard (one XCD's share).  One workgroup per
+// group bucket-sorts its tiles by list length, longest first: order[8*j + g] = j-th tile of group g.
+// Slots past the end of a group hold -1.  Which tile lands where inside a bucket is not deterministic;
+// nothing observable depends on it.
+__global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict__ ranges, const FrameCtrl *ctrl, int tiles_x,
+                                                         int row_begin, int row_step, int rows, int slots_per_group,
+                                                         int *__restrict__ order)
+{
+    __shared__ uint32_t bucket_cnt[64];
+    __shared__ uint32_t bucket_start[64];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int rows_g = g < rows ? (rows - g + 7) / 8 : 0;
+    const int n = rows_g * tiles_x;
+    const uint32_t max_len = max(ctrl->max_list_len, 1u);
+    if (tid < 64) bucket_cnt[tid] = 0;
+    for (int j = n + tid; j < slots_per_group; j += 256) order[8 * j + g] = -1;
+    __syncthreads();
+    auto tile_of = [&](int j) { return (row_begin + (g + 8 * (j / tiles_x)) * row_step) * tiles_x + (j % tiles_x); };
+    auto bucket_of = [&](int tile) {
+        const uint2 r = ranges[tile];
+        const uint32_t len = r.y - r.x;
+        return 63u - min(63u, (uint32_t)(((unsigned long long)len * 63ull) / max_len));
+    };
+    for (int j = tid; j < n; j += 256) atomicAdd(&bucket_cnt[bucket_of(tile_of(j))], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int b = 0; b < 64; ++b) { bucket_start[b] = acc; acc += bucket_cnt[b]; }
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += 256) {
+        const int tile = tile_of(j);
+        const uint32_t slot = atomicAdd(&bucket_start[bucket_of(tile)], 1u);
+        order[8 * (int)slot + g] = tile;
+    }
+}
+
 __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
 {
     __shared__ float4 s0[256];
@@ -44,17 +110,9 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
     __shared__ float4 s2[256];
     __shared__ int s_done;
 
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so workgroup b and b+8
-    // share an L2.  Give XCD k the tile rows k, k+8, ... of the shard: x-neighbours (which share most of
-    // their gaussians) hit the same L2, and heavy image regions are spread over all XCDs.
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, j = bid >> 3;
-    const int rows_per_xcd = (a.rows + 7) >> 3;
-    const int jr = j / a.tiles_x, tx = j - jr * a.tiles_x;
-    const int shard_row = xcd + 8 * jr;
-    if (jr >= rows_per_xcd || shard_row >= a.rows) return;  // uniform
-    const int ty = a.row_begin + shard_row * a.row_step;
-    const int tile = ty * a.tiles_x + tx;
+    const int tile = a.order[blockIdx.x];
+    if (tile < 0) return;  // uniform
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qx = tx * 16 + (wave & 1) * 8, qy = ty * 16 + (wave >> 1) * 8;
@@ -65,6 +123,7 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
     const uint2 range = a.ranges[tile];
     float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
     bool wave_done = false;
+    uint32_t evaluated = 0;  // wave-uniform
     if (tid == 0) s_done = 0;
 
     for (uint32_t batch = range.x; batch < range.y; batch += 256) {
@@ -73,39 +132,37 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
         const uint32_t i = batch + tid;
         if (i < range.y) {
             const GaussRec *r = a.rec + a.pval[i];
-            s0[tid] = r->r0;
-            s1[tid] = r->r1;
-            s2[tid] = r->r2;
+            s0[tid] = r->q0;
+            s1[tid] = r->q1;
+            s2[tid] = r->q2;
         }
         __syncthreads();
         if (wave_done) continue;
         const int nb = min(256u, range.y - batch);
         for (int chunk = 0; chunk < nb; chunk += 64) {
             const int e = chunk + lane;
-            bool hit = false;
-            if (e < nb) {
-                const float4 g0 = s0[e];
-                const float4 g2 = s2[e];
-                hit = (g0.x + g2.y >= qx0) & (g0.x - g2.y <= qx1) & (g0.y + g2.z >= qy0) & (g0.y - g2.z <= qy1);
-            }
+            const bool hit = e < nb && footprint_hits_rect(s0[e], s1[e], qx0, qx1, qy0, qy1);
             unsigned long long m = __ballot(hit);
+            evaluated += (uint32_t)__popcll(m);
             while (m) {
-                const int k = chunk + (__ffsll((long long)m) - 1);
+                const int k0 = chunk + (__ffsll((long long)m) - 1);
                 m &= m - 1;
-                const float4 g0 = s0[k];  // wave-uniform address: LDS broadcast
-                const float4 g1 = s1[k];
-                const float g2x = s2[k].x;
-                const float dx = g0.x - fpx, dy = g0.y - fpy;
-                const float power = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;  // log2 domain
-                float alpha = g1.y * __builtin_amdgcn_exp2f(power);
-                alpha = fminf(alpha, GSR_MAX_ALPHA);
-                const bool valid = (alpha > GSR_MIN_ALPHA) & (power <= 0.0f);
-                alpha = valid ? alpha : 0.0f;
-                const float w = alpha * T;
-                Cr = fmaf(w, g1.z, Cr);
-                Cg = fmaf(w, g1.w, Cg);
-                Cb = fmaf(w, g2x, Cb);
-                T = T * (1.0f - alpha);
+                const float2 ga = *reinterpret_cast<const float2 *>(&s0[k0]);  // wave-uniform address: LDS broadcast
+                const float4 ca = s1[k0];
+                const float4 oa = s2[k0];
+                asm volatile("" ::"v"(ca.w));  // keep the read a ds_read_b128 (4 LDS cycles); a b96 costs 8
+                if (m) {  // second survivor: its LDS reads are issued before the first one's arithmetic
+                    const int k1 = chunk + (__ffsll((long long)m) - 1);
+                    m &= m - 1;
+                    const float2 gb = *reinterpret_cast<const float2 *>(&s0[k1]);
+                    const float4 cb = s1[k1];
+                    const float4 ob = s2[k1];
+                    asm volatile("" ::"v"(cb.w));
+                    blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
+                    blend_one(gb, cb, ob, fpx, fpy, T, Cr, Cg, Cb);
+                } else {
+                    blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
+                }
             }
             if (a.early_T > 0.0f && __all(T < a.early_T)) {
                 wave_done = true;
@@ -115,6 +172,7 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
         }
     }
 
+    if (lane == 0 && evaluated) atomicAdd(&a.ctrl->wave_entries, (unsigned long long)evaluated);
     if (px < a.W && py < a.H) {
         const bool drawn = px < a.xlim && py < a.ylim;  // Q1: last column / row stay black, T stays 1
         const float r = drawn ? Cr : 0.0f, g = drawn ? Cg : 0.0f, b = drawn ? Cb : 0.0f;
@@ -141,6 +199,7 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     a.rec = ws.rec;
     a.out = out_image;
     a.out_T = out_T;
+    a.ctrl = ws.ctrl;
     a.W = cam.width; a.H = cam.height;
     a.xlim = opts.reference_compat ? cam.width - 1 : cam.width;
     a.ylim = opts.reference_compat ? cam.height - 1 : cam.height;
@@ -152,8 +211,11 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     a.early_T = opts.early_out_T;
     if (a.rows <= 0 || a.tiles_x <= 0) return GSR_OK;
     const int rows_per_xcd = (a.rows + 7) / 8;
-    const unsigned grid = 8u * (unsigned)rows_per_xcd * (unsigned)a.tiles_x;
-    hipLaunchKernelGGL(blend_kernel, dim3(grid), dim3(256), 0, s, a);
+    const int slots_per_group = rows_per_xcd * a.tiles_x;
+    a.order = ws.tile_order;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(256), 0, s, ws.ranges, ws.ctrl, a.tiles_x, a.row_begin, a.row_step, a.rows,
+                       slots_per_group, ws.tile_order);
+    hipLaunchKernelGGL(blend_kernel, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

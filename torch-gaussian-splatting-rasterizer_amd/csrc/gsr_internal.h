@@ -15,19 +15,20 @@ namespace gsr {
 struct FrameCtrl {
     uint32_t n_visible;     // V  (written by the first depth-sort scatter pass)
     uint32_t n_pairs_bbox;  // D  (total of the tile-count scan, before clamping)
-    uint32_t n_pairs;       // E  = min(D, max_pairs)
+    uint32_t n_pairs;       // E  (pairs that survive footprint culling; written by tile-sort pass 0)
     uint32_t overflow;
     uint32_t max_list_len;
-    uint32_t pad[3];
+    uint32_t n_slots;       // min(D, max_pairs): pair slots written by the emit kernel
+    unsigned long long wave_entries;  // (quadrant, entry) pairs evaluated by the blend
     uint32_t digit_tot[256]; // per-digit totals of the radix pass in flight
 };
 
-// Per-gaussian record consumed by the blend (48 B, three 16-B loads):
-//   r0 = {mean_x, mean_y, A, B}     power2(dx,dy) = A dx^2 + B dx dy + C dy^2   (log2 domain)
-//   r1 = {C, opacity, red, green}
-//   r2 = {blue, half_extent_x, half_extent_y, unused}   (AABB of the alpha > 1/255 footprint)
+// Per-gaussian record consumed by pair emission and the blend (48 B, three 16-B loads):
+//   q0 = {mean_x, mean_y, -B/(2C), -B/(2A)}   the two ratios locate the edge maxima in footprint.h
+//   q1 = {A, B, C, pthr}    power2(dx,dy) = A dx^2 + B dx dy + C dy^2 (log2 domain); pthr: see footprint.h
+//   q2 = {log2(opacity), red, green, blue}     alpha = 2^(power2 + log2(opacity))
 struct alignas(16) GaussRec {
-    float4 r0, r1, r2;
+    float4 q0, q1, q2;
 };
 
 constexpr int SORT_THREADS = 256;
@@ -48,6 +49,7 @@ struct Workspace {
     uint32_t *pkey[2];    // [max_pairs] tile ids
     uint32_t *pval[2];    // [max_pairs] gaussian ids
     uint2 *ranges;        // [tiles]
+    int *tile_order;      // [8 * ceil(tiles_y/8) * tiles_x] blend launch order
     int64_t n;
     int64_t max_pairs;
     int tiles_x, tiles_y;

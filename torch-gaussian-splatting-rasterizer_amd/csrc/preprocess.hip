@@ -222,13 +222,15 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
     // ellipse has the axis-aligned half extents sqrt(2 tau sy / D), sqrt(2 tau sx / D), D = sx sy - sxy^2.
     // Evaluated in fp64 from the fp32 conic the blend really uses, inflated (1 % on tau, 0.05 px) so that
     // rounding in the per-pixel fp32 evaluation can never put a contributing pixel outside.
-    float hx = 3.0e38f, hy = 3.0e38f;
+    float hx = 3.0e38f, hy = 3.0e38f, pthr = -3.0e38f;
     if (visible && !no_cull) {
         const double D = (double)sx * (double)sy - (double)sxy * (double)sxy;
         if (sx > 0.0f && sy > 0.0f && D > 0.0) {
-            const double tau2 = 2.0 * 1.01 * log(255.0 * (double)op);
+            const double tau = log(255.0 * (double)op);  // > 0 because op > 1/255
+            const double tau2 = 2.0 * 1.01 * tau;
             hx = (float)(sqrt(tau2 * (double)sy / D) * 1.0001 + 0.05);
             hy = (float)(sqrt(tau2 * (double)sx / D) * 1.0001 + 0.05);
+            pthr = (float)(-1.01 * tau * 1.4426950408889634 - 1.0e-3);  // -log2(255 op), loosened (footprint.h)
         }
     }
     // refine the reference rect [x_min,x_max) x [y_min,y_max) by the footprint; pixel centres are integers (Q9)
@@ -256,9 +258,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
     rect[i] = make_ushort4((unsigned short)tx0, (unsigned short)ty0, (unsigned short)tx1, (unsigned short)ty1);
     const float LOG2E = 1.4426950408889634f;
     GaussRec r;
-    r.r0 = make_float4(mx, my, (-0.5f * sx) * LOG2E, (-sxy) * LOG2E);
-    r.r1 = make_float4((-0.5f * sy) * LOG2E, op, rgb[0], rgb[1]);
-    r.r2 = make_float4(rgb[2], hx, hy, 0.0f);
+    const float A = (-0.5f * sx) * LOG2E, B = (-sxy) * LOG2E, C = (-0.5f * sy) * LOG2E;
+    // -B/(2C), -B/(2A): only used by the culling test, and only when the conic is positive definite (A, C < 0)
+    const float rc = pthr < -1e37f ? 0.0f : -0.5f * B / C, ra = pthr < -1e37f ? 0.0f : -0.5f * B / A;
+    r.q0 = make_float4(mx, my, rc, ra);
+    r.q1 = make_float4(A, B, C, pthr);
+    r.q2 = make_float4(log2f(op), rgb[0], rgb[1], rgb[2]);
     rec[i] = r;
 }
 

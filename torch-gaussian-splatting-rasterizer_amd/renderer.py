@@ -172,6 +172,14 @@ class Rasterizer:
                 continue
             return (img, final_T) if return_T else img
 
+    def fit_pairs(self, cam: GsrCamera, opts: Optional[GsrOptions] = None, slack: float = 1.25) -> int:
+        """Size the pair buffers to this view: one probing frame, then max_pairs = slack * D (+ margin).
+        Sort grids and histogram tables scale with max_pairs, so a snug bound is also the fast one."""
+        self.render(cam, opts)
+        need = int(self.last_stats["n_pairs_bbox"])
+        self.max_pairs = int(min(0xFFFFFFF0, max(4096, slack * need + 4096)))
+        return self.max_pairs
+
     # -- stage-by-stage (tests, helper functions) -------------------------------------------------
     def preprocess_debug(self, cam: GsrCamera, opts: Optional[GsrOptions] = None) -> Dict[str, torch.Tensor]:
         """Run stage 1 alone and return every per-gaussian intermediate the reference's helpers produce."""
