@@ -70,8 +70,10 @@ typedef struct GsrCamera {
 typedef struct GsrOptions {
     int32_t reference_compat; /* 1 (default): reproduce Q1 (column W-1 / row H-1 never drawn, rasterize.py:271-272,
                                  :415-418) and Q2 (skip if ANY conic entry == 0, :441).  0: draw every pixel. */
-    float early_out_T;        /* 0 (default) = blend every gaussian like the reference (Q5).  >0: a pixel stops
-                                 once its transmittance falls below this (an approximation; INRIA uses 1e-4). */
+    float early_out_T;        /* a wave of 64 pixels stops once all their transmittances are <= this.  0 (default) is
+                                 exact — identical bits to blending every gaussian like the reference (Q5), because
+                                 T == 0.0f makes every later contribution exactly zero.  >0 is a bounded
+                                 approximation (INRIA uses 1e-4). */
     int32_t tile_row_begin;   /* multi-GPU sharding: this call bins+blends tile rows begin, begin+step, ... */
     int32_t tile_row_step;    /* default 0 / 1 = all rows */
     int32_t output_layout;    /* 0 (default): image [H,W,3] (= screen.transpose(1,0), rasterize.py:471);

@@ -139,6 +139,19 @@ def test_pair_overflow_is_reported_and_recovered(G):
     assert small.max_pairs > 4096 and torch.equal(again, good)
 
 
+def test_saturation_early_out_is_exact(G):
+    """early_out_T = 0 stops a wave when all its pixels have T == 0.0f; a negative threshold never stops.
+    An opaque wall in front of a long list makes the early-out fire; the frames must be identical."""
+    cols, cam, _ = _medium(G, n=300_000, shift=1.6)
+    cols["opacity"] = np.full_like(cols["opacity"], 6.0)        # sigmoid(6) = 0.9975 -> alpha capped at 0.99
+    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
+    a, Ta = R.render(cam, return_T=True)
+    early = R.last_stats["wave_entries"]
+    b, Tb = R.render(cam, G.renderer.make_options(early_out_T=-1.0), return_T=True)
+    assert torch.equal(a, b) and torch.equal(Ta, Tb)
+    assert (Ta == 0).any() and early < R.last_stats["wave_entries"]
+
+
 def test_early_out_is_a_bounded_approximation(G):
     cols, cam, _ = _medium(G)
     R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
@@ -198,7 +211,7 @@ def test_tile_row_shards_reassemble_bit_exactly(G, step):
             out[ty * 16: ty * 16 + h] = strip[k * 16: k * 16 + h]
     assert torch.equal(out, full)
     R.render(cam)
-    assert pairs == R.last_stats["n_pairs"]
+    assert pairs >= R.last_stats["n_pairs"] > 0                 # shards cull per-tile a little less (smaller rects)
 
 
 def test_full_hd_one_million(G):

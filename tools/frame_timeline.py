@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Print the per-dispatch timeline of one steady-state frame from a rocprofv3 --kernel-trace CSV.
+usage: tools/frame_timeline.py <..._kernel_trace.csv> [frame_index_from_end=5]"""
+import csv
+import sys
+
+
+def main():
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    back = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    starts = [i for i, r in enumerate(rows) if "preprocess_kernel" in r["Kernel_Name"]]
+    s, e = starts[-back], starts[-back + 1]
+    t0 = int(rows[s]["Start_Timestamp"])
+    prev_end = None
+    total = 0.0
+    for r in rows[s:e]:
+        st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        gap = (st - prev_end) / 1e3 if prev_end else 0.0
+        total += (en - st) / 1e3
+        name = r["Kernel_Name"].replace("void ", "").replace("gsr::", "")[:44]
+        print(f"{(st - t0) / 1e3:9.1f} us  dur {(en - st) / 1e3:8.1f}  gap {gap:5.1f}  grid {int(r['Grid_Size_X']):>9d}  wg {r['Workgroup_Size_X']:>4s}  {name}")
+        prev_end = en
+    print(f"frame span {(prev_end - t0) / 1e3:.1f} us, sum of kernels {total:.1f} us, {e - s} dispatches")
+
+
+if __name__ == "__main__":
+    main()

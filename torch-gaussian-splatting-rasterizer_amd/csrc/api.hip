@@ -41,13 +41,16 @@ size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max
     ws->max_pairs = max_pairs;
     ws->tiles_x = (width + GSR_TILE - 1) / GSR_TILE;
     ws->tiles_y = (height + GSR_TILE - 1) / GSR_TILE;
-    ws->hist_blocks = (int)((std::max(nn, np) + SORT_TILE - 1) / SORT_TILE);
+    ws->hist_blocks = (int)std::max((nn + SORT_THREADS * DEPTH_SORT_ITEMS - 1) / (SORT_THREADS * DEPTH_SORT_ITEMS),
+                                    (np + SORT_THREADS * PAIR_SORT_ITEMS - 1) / (SORT_THREADS * PAIR_SORT_ITEMS));
     ws->ctrl = static_cast<FrameCtrl *>(take(sizeof(FrameCtrl)));
     ws->rec = static_cast<GaussRec *>(take(sizeof(GaussRec) * nn));
     ws->rect = static_cast<ushort4 *>(take(sizeof(ushort4) * nn));
     for (int b = 0; b < 2; ++b) ws->key[b] = static_cast<uint32_t *>(take(4 * nn));
     for (int b = 0; b < 2; ++b) ws->val[b] = static_cast<uint32_t *>(take(4 * nn));
-    ws->blk_sum = static_cast<uint32_t *>(take(4 * ((nn + EMIT_THREADS - 1) / EMIT_THREADS + 1)));
+    for (int b = 0; b < 2; ++b) ws->rect8[b] = static_cast<uint32_t *>(take(4 * nn));
+    ws->blk_sum = static_cast<uint32_t *>(
+        take(4 * ((std::max(nn, (size_t)ws->tiles_x * ws->tiles_y) + EMIT_THREADS - 1) / EMIT_THREADS + 1)));
     ws->hist = static_cast<uint32_t *>(take(4 * 256 * (size_t)ws->hist_blocks));
     for (int b = 0; b < 2; ++b) ws->pkey[b] = static_cast<uint32_t *>(take(4 * np));
     for (int b = 0; b < 2; ++b) ws->pval[b] = static_cast<uint32_t *>(take(4 * np));
@@ -217,14 +220,16 @@ int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_
     hipStream_t s = static_cast<hipStream_t>(stream);
     int buf = 0;
     // depth order: 4 x 8-bit passes over the 32 key bits; pass 0 drops culled gaussians and leaves V in ctrl
-    rc = launch_radix_sort(ws.key, ws.val, nullptr, n, 4, true, &ws.ctrl->n_visible, ws, &buf, s);
+    const bool packed = rect_fits_8bit(ws);
+    rc = launch_radix_sort(ws.key, ws.val, packed ? ws.rect8 : nullptr, nullptr, n, 4, true, &ws.ctrl->n_visible,
+                           DEPTH_SORT_ITEMS, ws, &buf, s);
     if (rc) return rc;
-    rc = launch_binning(*cam, *opts, ws, buf, s);
+    rc = launch_binning(*cam, *opts, ws, buf, packed, s);
     if (rc) return rc;
     int pbuf = 0;
     // tile lists: stable sort by tile id; pass 0 drops the pairs the emit kernel culled and leaves E in ctrl
-    rc = launch_radix_sort(ws.pkey, ws.pval, &ws.ctrl->n_slots, max_pairs, tile_sort_passes(ws.tiles_x * ws.tiles_y), true,
-                           &ws.ctrl->n_pairs, ws, &pbuf, s);
+    rc = launch_radix_sort(ws.pkey, ws.pval, nullptr, &ws.ctrl->n_slots, max_pairs, tile_sort_passes(ws.tiles_x * ws.tiles_y), true,
+                           &ws.ctrl->n_pairs, PAIR_SORT_ITEMS, ws, &pbuf, s);
     if (rc) return rc;
     return launch_tile_ranges(ws, pbuf, s);
 }

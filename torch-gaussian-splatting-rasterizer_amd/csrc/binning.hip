@@ -5,20 +5,27 @@
 // (BLOCK_SIZE, rasterize.py:34) of its rect so that tiles can be composited independently.
 //
 //   count   one thread per depth-sorted gaussian: tiles of its rect that belong to this shard
-//           (tile rows begin, begin+step, ...) -> per-workgroup sums
-//   scan    one workgroup: exclusive scan of the workgroup sums; D, overflow flag, E = min(D, max_pairs)
-//   emit    recount + in-workgroup scan -> pair offsets; small rects are written by their own lane,
-//           rects above 32 tiles by the whole wave (the tile count is heavy-tailed: median 4, max thousands).
-//           A tile the gaussian's alpha > 1/255 footprint cannot reach (footprint.h; rect corners of oblique
-//           ellipses) gets KEY_INVALID and is dropped by pass 0 of the tile sort.
+//           (tile rows begin, begin+step, ...) -> per-workgroup sums.  The rect arrives packed in the depth
+//           sort's second payload (coalesced); frames wider than 4096 px gather it by gaussian id instead.
+//   scan    one workgroup: exclusive scan of the workgroup sums; D, overflow flag, slots = min(D, max_pairs)
+//   emit    load-balanced expansion: a workgroup owns 256 consecutive gaussians and the contiguous slot range
+//           their pairs occupy; every thread takes slots j, j+256, ..., finds the owning gaussian by binary
+//           search over the workgroup's 256 offsets in LDS and writes (tile id, gaussian id) — coalesced stores,
+//           no divergence however heavy-tailed the rect sizes are (median 4 tiles, max thousands).
+//           Rects above CULL_MIN_TILES tiles are tested tile by tile against the gaussian's alpha > 1/255
+//           footprint (footprint.h): unreachable tiles (corners of oblique ellipses) get KEY_INVALID and are
+//           dropped by pass 0 of the tile sort.  Smaller rects skip the test (it needs a 32-B gather per
+//           gaussian; the blend culls per 8x8 quadrant anyway).
 //   ranges  boundaries of equal tile ids in the tile-sorted pair array -> ranges[tile] = [begin, end)
-// Roofline: HBM.  Bytes: 12 B per sorted gaussian (id + rect) + 8 B per pair written; ranges reads 4 B per pair.
+// Roofline: HBM.  Bytes: 8 B per sorted gaussian (id + rect) + 8 B per pair written; ranges reads 4 B per pair.
 #include <cstring>
 #include <algorithm>
 #include "gsr_internal.h"
 #include "footprint.h"
 
 namespace gsr {
+
+constexpr uint32_t CULL_MIN_TILES = 8;
 
 struct Shard {
     int begin, step;
@@ -44,17 +51,33 @@ __device__ __forceinline__ uint32_t tiles_of(ushort4 rc, Shard sh, int *first_ro
     return (uint32_t)rows * (uint32_t)(rc.z - rc.x);
 }
 
-__global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t *__restrict__ sorted_ids, const FrameCtrl *ctrl,
+__device__ __forceinline__ ushort4 unpack_rect8(uint32_t r)
+{
+    return make_ushort4((unsigned short)(r & 255u), (unsigned short)((r >> 8) & 255u), (unsigned short)(((r >> 16) & 255u) + 1u),
+                        (unsigned short)((r >> 24) + 1u));
+}
+
+template <bool PACKED>
+__device__ __forceinline__ ushort4 rect_of(uint32_t r, const uint32_t *sorted_ids, const uint32_t *sorted_rect8, const ushort4 *rect)
+{
+    return PACKED ? unpack_rect8(sorted_rect8[r]) : rect[sorted_ids[r]];
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t *__restrict__ sorted_ids,
+                                                                  const uint32_t *__restrict__ sorted_rect8, const FrameCtrl *ctrl,
                                                                   const ushort4 *__restrict__ rect, Shard sh,
-                                                                  uint32_t *__restrict__ blk_sum)
+                                                                  uint32_t *__restrict__ blk_sum, uint2 *__restrict__ ranges,
+                                                                  int n_tiles)
 {
     __shared__ uint32_t scratch[8];
     const uint32_t n = ctrl->n_visible;
     const uint32_t r = blockIdx.x * EMIT_THREADS + threadIdx.x;
+    if (r < (uint32_t)n_tiles) ranges[r] = make_uint2(0u, 0u);  // tile ranges are rebuilt every frame
     uint32_t cnt = 0;
     if (r < n) {
         int first;
-        cnt = tiles_of(rect[sorted_ids[r]], sh, &first);
+        cnt = tiles_of(rect_of<PACKED>(r, sorted_ids, sorted_rect8, rect), sh, &first);
     }
     uint32_t total;
     block_excl_scan_256(cnt, scratch, &total);
@@ -106,66 +129,65 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(uint32_t *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t *__restrict__ sorted_ids, const FrameCtrl *ctrl,
+template <bool PACKED>
+__global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t *__restrict__ sorted_ids,
+                                                                 const uint32_t *__restrict__ sorted_rect8, const FrameCtrl *ctrl,
                                                                  const ushort4 *__restrict__ rect, Shard sh, int tiles_x,
                                                                  const GaussRec *__restrict__ rec,
                                                                  const uint32_t *__restrict__ blk_off, uint32_t max_pairs,
                                                                  uint32_t *__restrict__ pkey, uint32_t *__restrict__ pval)
 {
     __shared__ uint32_t scratch[8];
+    __shared__ uint32_t s_off[EMIT_THREADS];   // exclusive pair offset of each gaussian inside the workgroup
+    __shared__ uint32_t s_id[EMIT_THREADS];
+    __shared__ uint32_t s_geo[EMIT_THREADS];   // x0 | width << 16
+    __shared__ int s_first[EMIT_THREADS];      // first tile row of the shard, or -1 - first when the rect is culled per tile
+    __shared__ float4 s_q0[EMIT_THREADS];
+    __shared__ float4 s_q1[EMIT_THREADS];
     const uint32_t n = ctrl->n_visible;
-    const uint32_t r = blockIdx.x * EMIT_THREADS + threadIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t r = blockIdx.x * EMIT_THREADS + tid;
     if (blockIdx.x * EMIT_THREADS >= n) return;  // uniform
     uint32_t cnt = 0, g = 0;
     int first = 0;
     ushort4 rc = make_ushort4(0, 0, 0, 0);
-    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
     if (r < n) {
         g = sorted_ids[r];
-        rc = rect[g];
+        rc = rect_of<PACKED>(r, sorted_ids, sorted_rect8, rect);
         cnt = tiles_of(rc, sh, &first);
-        if (cnt > 0) { q0 = rec[g].q0; q1 = rec[g].q1; }
     }
+    const bool test = cnt > CULL_MIN_TILES;
+    if (test) { s_q0[tid] = rec[g].q0; s_q1[tid] = rec[g].q1; }
     uint32_t total;
-    const uint32_t off = blk_off[blockIdx.x] + block_excl_scan_256(cnt, scratch, &total);
-    const int width = rc.z - rc.x;
+    s_off[tid] = block_excl_scan_256(cnt, scratch, &total);
+    s_id[tid] = g;
+    s_geo[tid] = (uint32_t)rc.x | ((uint32_t)(rc.z - rc.x) << 16);
+    s_first[tid] = test ? -1 - first : first;
+    __syncthreads();
 
-    constexpr uint32_t WAVE_COOP = 32;  // rects above this many tiles are written by all 64 lanes
-    // -- large rects: one at a time, the whole wave strides over its tiles
-    unsigned long long big = __ballot(cnt > WAVE_COOP);
-    const int lane = threadIdx.x & 63;
-    while (big) {
-        const int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        const uint32_t b_cnt = __shfl(cnt, src, 64), b_off = __shfl(off, src, 64), b_g = __shfl(g, src, 64);
-        const int b_w = __shfl(width, src, 64), b_x0 = __shfl((int)rc.x, src, 64), b_first = __shfl(first, src, 64);
-        const float4 b_q0 = make_float4(__shfl(q0.x, src, 64), __shfl(q0.y, src, 64), __shfl(q0.z, src, 64), __shfl(q0.w, src, 64));
-        const float4 b_q1 = make_float4(__shfl(q1.x, src, 64), __shfl(q1.y, src, 64), __shfl(q1.z, src, 64), __shfl(q1.w, src, 64));
-        for (uint32_t k = lane; k < b_cnt; k += 64) {
-            const uint32_t row = k / (uint32_t)b_w, col = k - row * (uint32_t)b_w;
-            const uint32_t o = b_off + k;
-            if (o < max_pairs) {
-                const int tyy = b_first + (int)row * sh.step, txx = b_x0 + (int)col;
-                const bool hit = footprint_hits_rect(b_q0, b_q1, (float)(txx * 16), (float)(txx * 16 + 15), (float)(tyy * 16),
-                                                     (float)(tyy * 16 + 15));
-                pkey[o] = hit ? (uint32_t)tyy * (uint32_t)tiles_x + (uint32_t)txx : KEY_INVALID;
-                pval[o] = b_g;
-            }
-        }
-    }
-    // -- small rects: each lane writes its own
-    if (cnt > 0 && cnt <= WAVE_COOP) {
-        uint32_t o = off;
-        int ty = first;
-        for (; ty < rc.w; ty += sh.step) {
-            for (int tx = rc.x; tx < rc.z; ++tx, ++o) {
-                if (o < max_pairs) {
-                    const bool hit = footprint_hits_rect(q0, q1, (float)(tx * 16), (float)(tx * 16 + 15),
-                                                                     (float)(ty * 16), (float)(ty * 16 + 15));
-                    pkey[o] = hit ? (uint32_t)ty * (uint32_t)tiles_x + (uint32_t)tx : KEY_INVALID;
-                    pval[o] = g;
-                }
-            }
+    const uint32_t base = blk_off[blockIdx.x];
+    for (uint32_t j = tid; j < total; j += EMIT_THREADS) {
+        // owner = last gaussian whose offset is <= j (zero-count gaussians share an offset with their successor)
+        int lo = 0;
+#pragma unroll
+        for (int step = EMIT_THREADS / 2; step >= 1; step >>= 1)
+            if (s_off[lo + step] <= j) lo += step;
+        const uint32_t k = j - s_off[lo];
+        const uint32_t geo = s_geo[lo];
+        const uint32_t w = geo >> 16;
+        uint32_t row = (uint32_t)((float)k / (float)w);  // k < 2^24: exact up to the rounding fixed below
+        if (row * w > k) --row;
+        else if ((row + 1) * w <= k) ++row;
+        const uint32_t col = k - row * w;
+        const int fr = s_first[lo];
+        const bool tested = fr < 0;
+        const int ty = (tested ? -1 - fr : fr) + (int)row * sh.step, tx = (int)(geo & 0xFFFFu) + (int)col;
+        const uint32_t o = base + j;
+        if (o < max_pairs) {
+            const bool hit = !tested || footprint_hits_rect(s_q0[lo], s_q1[lo], (float)(tx * 16), (float)(tx * 16 + 15),
+                                                            (float)(ty * 16), (float)(ty * 16 + 15));
+            pkey[o] = hit ? (uint32_t)ty * (uint32_t)tiles_x + (uint32_t)tx : KEY_INVALID;
+            pval[o] = s_id[lo];
         }
     }
 }
@@ -183,18 +205,6 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t *__rest
     }
 }
 
-__global__ __launch_bounds__(256) void max_list_kernel(const uint2 *__restrict__ ranges, int n_tiles, FrameCtrl *ctrl)
-{
-    uint32_t m = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_tiles; i += gridDim.x * blockDim.x) {
-        const uint2 r = ranges[i];
-        m = max(m, r.y - r.x);
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&ctrl->max_list_len, m);
-}
-
 int tile_sort_passes(int tiles)
 {
     int bits = 1;
@@ -202,18 +212,34 @@ int tile_sort_passes(int tiles)
     return (bits + 7) / 8;
 }
 
-int launch_binning(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int sorted_buf, hipStream_t s)
+int launch_binning(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int sorted_buf, bool packed_rect,
+                   hipStream_t s)
 {
     (void)cam;
     if (ws.n <= 0) return GSR_OK;
     const Shard sh = {opts.tile_row_begin, opts.tile_row_step < 1 ? 1 : opts.tile_row_step};
-    const int nblk = (int)((ws.n + EMIT_THREADS - 1) / EMIT_THREADS);
+    const int n_tiles = ws.tiles_x * ws.tiles_y;
+    // the count kernel also zeroes ranges[]: make sure its grid covers them
+    const int nblk = (int)((std::max<int64_t>(ws.n, n_tiles) + EMIT_THREADS - 1) / EMIT_THREADS);
+    const int nblk_n = (int)((ws.n + EMIT_THREADS - 1) / EMIT_THREADS);
     const uint32_t *ids = ws.val[sorted_buf];
+    const uint32_t *r8 = ws.rect8[sorted_buf];
     const uint32_t cap = (uint32_t)ws.max_pairs;
-    hipLaunchKernelGGL(pair_count_kernel, dim3(nblk), dim3(EMIT_THREADS), 0, s, ids, ws.ctrl, ws.rect, sh, ws.blk_sum);
-    hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, ws.blk_sum, nblk, ws.ctrl, cap);
-    hipLaunchKernelGGL(pair_emit_kernel, dim3(nblk), dim3(EMIT_THREADS), 0, s, ids, ws.ctrl, ws.rect, sh, ws.tiles_x, ws.rec,
-                       ws.blk_sum, cap, ws.pkey[0], ws.pval[0]);
+    if (packed_rect) {
+        hipLaunchKernelGGL(pair_count_kernel<true>, dim3(nblk), dim3(EMIT_THREADS), 0, s, ids, r8, ws.ctrl, ws.rect, sh, ws.blk_sum,
+                           ws.ranges, n_tiles);
+    } else {
+        hipLaunchKernelGGL(pair_count_kernel<false>, dim3(nblk), dim3(EMIT_THREADS), 0, s, ids, r8, ws.ctrl, ws.rect, sh, ws.blk_sum,
+                           ws.ranges, n_tiles);
+    }
+    hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, ws.blk_sum, nblk_n, ws.ctrl, cap);
+    if (packed_rect) {
+        hipLaunchKernelGGL(pair_emit_kernel<true>, dim3(nblk_n), dim3(EMIT_THREADS), 0, s, ids, r8, ws.ctrl, ws.rect, sh, ws.tiles_x,
+                           ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0]);
+    } else {
+        hipLaunchKernelGGL(pair_emit_kernel<false>, dim3(nblk_n), dim3(EMIT_THREADS), 0, s, ids, r8, ws.ctrl, ws.rect, sh, ws.tiles_x,
+                           ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0]);
+    }
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }
@@ -221,11 +247,13 @@ int launch_binning(const GsrCamera &cam, const GsrOptions &opts, const Workspace
 int launch_tile_ranges(const Workspace &ws, int pair_buf, hipStream_t s)
 {
     const int n_tiles = ws.tiles_x * ws.tiles_y;
-    GSR_HIP(hipMemsetAsync(ws.ranges, 0, sizeof(uint2) * (size_t)n_tiles, s));
+    if (ws.n <= 0) {  // no count kernel ran: clear the ranges here
+        GSR_HIP(hipMemsetAsync(ws.ranges, 0, sizeof(uint2) * (size_t)n_tiles, s));
+        return GSR_OK;
+    }
     if (ws.max_pairs <= 0) return GSR_OK;
     const int grid = (int)std::min<int64_t>((ws.max_pairs + 255) / 256, 4096);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(grid), dim3(256), 0, s, ws.pkey[pair_buf], ws.ctrl, ws.ranges, n_tiles);
-    hipLaunchKernelGGL(max_list_kernel, dim3(std::min((n_tiles + 255) / 256, 64)), dim3(256), 0, s, ws.ranges, n_tiles, ws.ctrl);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

@@ -13,9 +13,11 @@
 //   - per pixel the reference's arithmetic: power (log2 domain, coefficients pre-scaled in preprocess),
 //     alpha = min(opacity * 2^power, 0.99), contribute iff alpha > 1/255 and power <= 0 (:285-291),
 //     C += alpha * T * rgb, T *= 1 - alpha (:295-303);
-//   - optional early-out (opts.early_out_T > 0): a wave whose 64 pixels are all below the threshold
-//     stops (wave ballot); the workgroup stops fetching once all four waves have.
-// No early termination by default: the reference blends every gaussian (Q5).
+//   - saturation early-out by wave ballot: a wave stops once T <= opts.early_out_T holds for all its 64 pixels,
+//     the workgroup stops fetching once all four waves have.  The default threshold 0 is EXACT, not an
+//     approximation of the reference's "blend every gaussian" (Q5): transmittance only ever shrinks, and once it
+//     has underflowed to 0.0f (a few dozen near-opaque layers) alpha*T*rgb = 0 and T stays 0 — the remaining
+//     entries cannot change a bit.  early_out_T > 0 (INRIA uses 1e-4) is the usual bounded approximation.
 //
 // Launch order: list lengths are heavy-tailed (longest ~3.5x the mean) and a frame is only ~4 rounds of
 // resident workgroups, so tiles are launched longest-first (tile_order_kernel: per XCD group, bucketed by
@@ -67,40 +69,46 @@ __device__ __forceinline__ void blend_one(const float2 g, const float4 c, const 
 }
 
 // Tile launch order.  Group g = tile rows g, g+8, ... of the shard (one XCD's share).  One workgroup per
-// group bucket-sorts its tiles by list length, longest first: order[8*j + g] = j-th tile of group g.
-// Slots past the end of a group hold -1.  Which tile lands where inside a bucket is not deterministic;
-// nothing observable depends on it.
-__global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict__ ranges, const FrameCtrl *ctrl, int tiles_x,
+// group bucket-sorts its tiles by list length, longest first (buckets = exponent + 3 mantissa bits of the
+// length, i.e. within 12.5 %): order[8*j + g] = j-th tile of group g.  Slots past the end of a group hold -1.
+// Which tile lands where inside a bucket is not deterministic; nothing observable depends on it.
+// Also leaves the longest list length in ctrl (stats).
+__global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict__ ranges, FrameCtrl *ctrl, int tiles_x,
                                                          int row_begin, int row_step, int rows, int slots_per_group,
                                                          int *__restrict__ order)
 {
-    __shared__ uint32_t bucket_cnt[64];
-    __shared__ uint32_t bucket_start[64];
+    constexpr int NB = 256;
+    __shared__ uint32_t bucket_cnt[NB];
+    __shared__ uint32_t bucket_start[NB];
+    __shared__ uint32_t scratch[8];
     const int g = blockIdx.x, tid = threadIdx.x;
     const int rows_g = g < rows ? (rows - g + 7) / 8 : 0;
     const int n = rows_g * tiles_x;
-    const uint32_t max_len = max(ctrl->max_list_len, 1u);
-    if (tid < 64) bucket_cnt[tid] = 0;
+    bucket_cnt[tid] = 0;
     for (int j = n + tid; j < slots_per_group; j += 256) order[8 * j + g] = -1;
     __syncthreads();
     auto tile_of = [&](int j) { return (row_begin + (g + 8 * (j / tiles_x)) * row_step) * tiles_x + (j % tiles_x); };
-    auto bucket_of = [&](int tile) {
-        const uint2 r = ranges[tile];
-        const uint32_t len = r.y - r.x;
-        return 63u - min(63u, (uint32_t)(((unsigned long long)len * 63ull) / max_len));
-    };
-    for (int j = tid; j < n; j += 256) atomicAdd(&bucket_cnt[bucket_of(tile_of(j))], 1u);
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (int b = 0; b < 64; ++b) { bucket_start[b] = acc; acc += bucket_cnt[b]; }
+    auto len_of = [&](int tile) { const uint2 r = ranges[tile]; return r.y - r.x; };
+    // lengths < 2^24: float conversion is exact; bits >> 20 = exponent (8 bits) and 3 mantissa bits, monotone in len
+    auto bucket_of = [&](uint32_t len) { return len == 0 ? (uint32_t)(NB - 1) : min((uint32_t)(NB - 2), (151u << 3) - (__float_as_uint((float)len) >> 20)); };
+    uint32_t longest = 0;
+    for (int j = tid; j < n; j += 256) {
+        const uint32_t len = len_of(tile_of(j));
+        longest = max(longest, len);
+        atomicAdd(&bucket_cnt[bucket_of(len)], 1u);
     }
+    __syncthreads();
+    uint32_t total;
+    bucket_start[tid] = block_excl_scan_256(bucket_cnt[tid], scratch, &total);
     __syncthreads();
     for (int j = tid; j < n; j += 256) {
         const int tile = tile_of(j);
-        const uint32_t slot = atomicAdd(&bucket_start[bucket_of(tile)], 1u);
+        const uint32_t slot = atomicAdd(&bucket_start[bucket_of(len_of(tile))], 1u);
         order[8 * (int)slot + g] = tile;
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, d, 64));
+    if ((tid & 63) == 0 && longest > 0) atomicMax(&ctrl->max_list_len, longest);
 }
 
 __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
 
     for (uint32_t batch = range.x; batch < range.y; batch += 256) {
         __syncthreads();  // previous batch fully consumed (and s_done initialised)
-        if (a.early_T > 0.0f && s_done == 4) break;  // uniform: every wave saturated
+        if (s_done == 4) break;  // uniform: every wave saturated
         const uint32_t i = batch + tid;
         if (i < range.y) {
             const GaussRec *r = a.rec + a.pval[i];
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
                     blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
                 }
             }
-            if (a.early_T > 0.0f && __all(T < a.early_T)) {
+            if (__all(T <= a.early_T)) {
                 wave_done = true;
                 if (lane == 0) atomicAdd(&s_done, 1);
                 break;

@@ -32,8 +32,8 @@ struct alignas(16) GaussRec {
 };
 
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = 16;
-constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // keys per workgroup per radix pass
+constexpr int DEPTH_SORT_ITEMS = 16;  // keys per thread per pass (2048-key tiles measured slower: fixed per-workgroup costs dominate)
+constexpr int PAIR_SORT_ITEMS = 16;
 constexpr int EMIT_THREADS = 256;                     // gaussians per workgroup in count/emit
 constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
 
@@ -41,6 +41,8 @@ struct Workspace {
     FrameCtrl *ctrl;
     GaussRec *rec;        // [n]
     ushort4 *rect;        // [n]   tile rect {tx0, ty0, tx1, ty1} (exclusive upper), after footprint refinement
+    uint32_t *rect8[2];   // [n]   the same rect packed x0 | y0<<8 | (x1-1)<<16 | (y1-1)<<24; rides through the depth
+                          //       sort as a second payload when the tile grid fits 8 bits (frames up to 4096 px)
     uint32_t *key[2];     // [n]   depth keys (ping-pong)
     uint32_t *val[2];     // [n]   gaussian ids (ping-pong)
     uint32_t *pair_off;   // [n]   exclusive pair offsets in depth order
@@ -79,10 +81,14 @@ int launch_cov3d(int64_t n, const float *log_scales, const float *quats, float *
 // n_dev: device pointer to the element count (may be nullptr -> n_bound is the count).
 // drop_invalid_first: pass 0 drops keys == KEY_INVALID and stores the survivor count to n_out (device).
 // On return *result_buf (0/1) tells which of key[]/val[] holds the sorted data.
-int launch_radix_sort(uint32_t *const key[2], uint32_t *const val[2], const uint32_t *n_dev, int64_t n_bound, int passes,
-                      bool drop_invalid_first, uint32_t *n_out, const Workspace &ws, int *result_buf, hipStream_t s);
+// val2 (may be nullptr): a second u32 payload moved along with val.  items_per_thread: 8 or 16.
+int launch_radix_sort(uint32_t *const key[2], uint32_t *const val[2], uint32_t *const val2[2], const uint32_t *n_dev,
+                      int64_t n_bound, int passes, bool drop_invalid_first, uint32_t *n_out, int items_per_thread,
+                      const Workspace &ws, int *result_buf, hipStream_t s);
 
-int launch_binning(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int sorted_buf, hipStream_t s);
+int launch_binning(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int sorted_buf, bool packed_rect,
+                   hipStream_t s);
+inline bool rect_fits_8bit(const Workspace &ws) { return ws.tiles_x <= 256 && ws.tiles_y <= 256; }
 int launch_tile_ranges(const Workspace &ws, int pair_buf, hipStream_t s);
 int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int pair_buf, float *out_image,
                  float *out_T, hipStream_t s);

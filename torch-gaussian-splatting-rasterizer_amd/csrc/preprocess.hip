@@ -106,7 +106,7 @@ __device__ __forceinline__ void load_sh48(const float *sh, int64_t i, float out[
 
 template <bool DEBUG>
 __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, GaussRec *__restrict__ rec,
-                                                         ushort4 *__restrict__ rect, uint32_t *__restrict__ depth_key,
+                                                         ushort4 *__restrict__ rect, uint32_t *__restrict__ rect8, uint32_t *__restrict__ depth_key,
                                                          uint32_t *__restrict__ ident, GsrDebugOut dbg)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
     if (!visible) { depth_key[i] = KEY_INVALID; return; }
     depth_key[i] = __float_as_uint(cm[2]);  // z >= 0.2 > 0: IEEE bits are monotone in z (rasterize.py:424-425)
     rect[i] = make_ushort4((unsigned short)tx0, (unsigned short)ty0, (unsigned short)tx1, (unsigned short)ty1);
+    rect8[i] = (uint32_t)(tx0 & 255) | ((uint32_t)(ty0 & 255) << 8) | ((uint32_t)((tx1 - 1) & 255) << 16) | ((uint32_t)((ty1 - 1) & 255) << 24);
     const float LOG2E = 1.4426950408889634f;
     GaussRec r;
     const float A = (-0.5f * sx) * LOG2E, B = (-sxy) * LOG2E, C = (-0.5f * sy) * LOG2E;
@@ -288,10 +289,10 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
     if (dbg) {
         d = *dbg;
         hipLaunchKernelGGL(preprocess_kernel<true>, dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat, opts.no_footprint_cull, ws.rec,
-                           ws.rect, ws.key[0], ws.val[0], d);
+                           ws.rect, ws.rect8[0], ws.key[0], ws.val[0], d);
     } else {
         hipLaunchKernelGGL(preprocess_kernel<false>, dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat, opts.no_footprint_cull, ws.rec,
-                           ws.rect, ws.key[0], ws.val[0], d);
+                           ws.rect, ws.rect8[0], ws.key[0], ws.val[0], d);
     }
     GSR_HIP(hipGetLastError());
     return GSR_OK;

@@ -1,20 +1,23 @@
-// sort.hip — stable LSD radix sort of (u32 key, u32 value) pairs, 8 bits per pass.
+// sort.hip — stable LSD radix sort of (u32 key, u32 value[, u32 value2]) records, 8 bits per pass.
 //
 // Used twice per frame (rasterize.py:424-425 is one torch.sort; tile lists have no reference counterpart):
 //   1. depth order:  keys = IEEE bits of z_cam of every gaussian (KEY_INVALID for culled ones, dropped
-//      by pass 0), values = gaussian id.  Stable from index order => depth ties resolve by index.
-//   2. tile lists:   keys = tile id of every (gaussian,tile) pair emitted IN DEPTH ORDER, values =
-//      gaussian id.  A stable sort by tile therefore leaves every tile's list depth-ordered.
+//      by pass 0), values = gaussian id (+ its packed tile rect).  Stable from index order => depth ties
+//      resolve by gaussian index.
+//   2. tile lists:   keys = tile id of every (gaussian,tile) pair emitted IN DEPTH ORDER (KEY_INVALID for pairs
+//      the emit kernel culled, dropped by pass 0), values = gaussian id.  A stable sort by tile therefore leaves
+//      every tile's list depth-ordered.
 //
 // Per pass, three launches (no inter-workgroup hand-off inside a launch, so nothing depends on dispatch
 // order or XCD placement):
-//   hist     one workgroup per 4096-key tile: 256-bin digit histogram -> hist[digit][tile]
+//   hist     one workgroup per tile of 256*ITEMS keys: 256-bin digit histogram -> hist[digit][tile]
 //   rowscan  one workgroup per digit: exclusive scan of its row in place, row total -> digit_tot[digit]
 //   scatter  one workgroup per tile: wave-ballot ranking -> tile reordered by digit in LDS -> digit runs
 //            written out contiguously (coalesced), position = digit base + scanned hist + rank in run
 // The element count lives in device memory (n_dev): grids are sized by the host-side bound and
-// surplus workgroups fall through.
-// Roofline: HBM.  Per pass per element: 4 B (hist) + 8 B read + 8 B written.
+// surplus workgroups fall through.  4096-key tiles (16 keys per thread): 2048-key tiles measured slower, the
+// fixed per-workgroup costs (7 barriers, two 256-wide scans, 512 table loads) dominate small tiles.
+// Roofline: HBM.  Per pass per element: 4 B (hist) + 8..12 B read + 8..12 B written.
 #include "gsr_internal.h"
 
 namespace gsr {
@@ -26,7 +29,7 @@ __device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t n
     return n < n_bound ? n : n_bound;
 }
 
-template <bool DROP_INVALID>
+template <bool DROP_INVALID, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t *__restrict__ keys, const uint32_t *n_dev,
                                                                   uint32_t n_bound, int shift, uint32_t *__restrict__ hist,
                                                                   int hist_blocks)
@@ -35,10 +38,10 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
     const uint32_t n = load_count(n_dev, n_bound);
     h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * SORT_TILE;
+    const uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
     if (base < n) {
 #pragma unroll
-        for (int r = 0; r < SORT_ITEMS; ++r) {
+        for (int r = 0; r < ITEMS; ++r) {
             const uint32_t idx = base + r * SORT_THREADS + threadIdx.x;
             if (idx < n) {
                 const uint32_t k = keys[idx];
@@ -75,25 +78,25 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t *__restrict
     if (threadIdx.x == 0) digit_tot[blockIdx.x] = carry;
 }
 
-template <bool DROP_INVALID>
-__global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint32_t *__restrict__ keys_in,
-                                                                     const uint32_t *__restrict__ vals_in,
-                                                                     uint32_t *__restrict__ keys_out,
-                                                                     uint32_t *__restrict__ vals_out, const uint32_t *n_dev,
-                                                                     uint32_t n_bound, int shift,
-                                                                     const uint32_t *__restrict__ hist, int hist_blocks,
-                                                                     const uint32_t *__restrict__ digit_tot, uint32_t *n_out)
+template <bool DROP_INVALID, int ITEMS, bool HAS_V2>
+__global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint32_t *__restrict__ vals2_in,
+    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t *__restrict__ vals2_out, const uint32_t *n_dev,
+    uint32_t n_bound, int shift, const uint32_t *__restrict__ hist, int hist_blocks, const uint32_t *__restrict__ digit_tot,
+    uint32_t *n_out)
 {
+    constexpr int TILE = SORT_THREADS * ITEMS;
     __shared__ uint32_t wave_cnt[4][256];   // per-wave digit counts, then per-wave exclusive bases
     __shared__ uint32_t digit_base[256];    // global position of this tile's run of digit d
     __shared__ uint32_t tile_start[256];    // start of digit d inside the reordered tile
-    __shared__ uint32_t skey[SORT_TILE];
-    __shared__ uint32_t sval[SORT_TILE];
+    __shared__ uint32_t skey[TILE];
+    __shared__ uint32_t sval[TILE];
+    __shared__ uint32_t sval2[HAS_V2 ? TILE : 1];
     __shared__ uint32_t scratch[8];
     __shared__ uint32_t s_valid;
 
     const uint32_t n = load_count(n_dev, n_bound);
-    const uint32_t base = blockIdx.x * SORT_TILE;
+    const uint32_t base = blockIdx.x * TILE;
     if (base >= n) return;  // uniform per workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -102,21 +105,21 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
     for (int w = 0; w < 4; ++w) wave_cnt[w][tid] = 0;
     __syncthreads();
 
-    // wave w owns items [w*1024, (w+1)*1024) of the tile, 16 rounds of 64 consecutive keys:
+    // wave w owns items [w*64*ITEMS, (w+1)*64*ITEMS) of the tile, ITEMS rounds of 64 consecutive keys:
     // tile order == (wave, round, lane) order, which is what keeps the sort stable.
-    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
+    uint32_t key[ITEMS], val[ITEMS], val2[HAS_V2 ? ITEMS : 1], rank[ITEMS];
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const uint32_t idx = base + wave * (64 * SORT_ITEMS) + r * 64 + lane;
+    for (int r = 0; r < ITEMS; ++r) {
+        const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
         const bool in = idx < n;
         key[r] = in ? keys_in[idx] : KEY_INVALID;
         val[r] = in ? vals_in[idx] : 0u;
-        if (!DROP_INVALID && !in) rank[r] = 0xFFFFFFFFu;  // marks padding when invalid keys are legal data
+        if (HAS_V2) val2[r] = in ? vals2_in[idx] : 0u;
     }
     volatile uint32_t *wc = wave_cnt[wave];
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const uint32_t idx = base + wave * (64 * SORT_ITEMS) + r * 64 + lane;
+    for (int r = 0; r < ITEMS; ++r) {
+        const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
         const bool valid = (idx < n) && (!DROP_INVALID || key[r] != KEY_INVALID);
         const uint32_t d = (key[r] >> shift) & 255u;
         unsigned long long m = __ballot(valid);
@@ -153,12 +156,13 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
     __syncthreads();
 
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         if (rank[r] != 0xFFFFFFFFu) {
             const uint32_t d = (key[r] >> shift) & 255u;
             const uint32_t pos = tile_start[d] + wave_cnt[wave][d] + rank[r];
             skey[pos] = key[r];
             sval[pos] = val[r];
+            if (HAS_V2) sval2[pos] = val2[r];
         }
     }
     __syncthreads();
@@ -170,41 +174,58 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
         const uint32_t gpos = digit_base[d] + (i - tile_start[d]);
         keys_out[gpos] = k;
         vals_out[gpos] = sval[i];
+        if (HAS_V2) vals2_out[gpos] = sval2[i];
     }
 }
 
-int launch_radix_sort(uint32_t *const key[2], uint32_t *const val[2], const uint32_t *n_dev, int64_t n_bound, int passes,
-                      bool drop_invalid_first, uint32_t *n_out, const Workspace &ws, int *result_buf, hipStream_t s)
+template <int ITEMS, bool HAS_V2>
+static int sort_passes(uint32_t *const key[2], uint32_t *const val[2], uint32_t *const val2[2], const uint32_t *n_dev,
+                       int64_t n_bound, int passes, bool drop_invalid_first, uint32_t *n_out, const Workspace &ws,
+                       int *result_buf, hipStream_t s)
 {
-    int cur = 0;
-    *result_buf = 0;
-    if (n_bound <= 0 || passes <= 0) return GSR_OK;
-    const int nblk = (int)((n_bound + SORT_TILE - 1) / SORT_TILE);
+    constexpr int TILE = SORT_THREADS * ITEMS;
+    const int nblk = (int)((n_bound + TILE - 1) / TILE);
     if (nblk > ws.hist_blocks) { set_error("radix sort: %d tiles exceed the histogram stride %d", nblk, ws.hist_blocks); return GSR_ERR_WORKSPACE; }
+    int cur = 0;
     const uint32_t *cnt_dev = n_dev;
+    uint32_t *dt = ws.ctrl->digit_tot;
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
         const bool drop = drop_invalid_first && p == 0;
-        uint32_t *dt = ws.ctrl->digit_tot;
+        const uint32_t *v2i = HAS_V2 ? val2[cur] : nullptr;
+        uint32_t *v2o = HAS_V2 ? val2[cur ^ 1] : nullptr;
         if (drop) {
-            hipLaunchKernelGGL(radix_hist_kernel<true>, dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], cnt_dev, (uint32_t)n_bound,
-                               shift, ws.hist, ws.hist_blocks);
+            hipLaunchKernelGGL((radix_hist_kernel<true, ITEMS>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], cnt_dev,
+                               (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks);
             hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, s, ws.hist, ws.hist_blocks, nblk, dt);
-            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], val[cur], key[cur ^ 1],
-                               val[cur ^ 1], cnt_dev, (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks, dt, n_out);
+            hipLaunchKernelGGL((radix_scatter_kernel<true, ITEMS, HAS_V2>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], val[cur],
+                               v2i, key[cur ^ 1], val[cur ^ 1], v2o, cnt_dev, (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks,
+                               dt, n_out);
             if (n_out) cnt_dev = n_out;  // later passes only see the survivors
         } else {
-            hipLaunchKernelGGL(radix_hist_kernel<false>, dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], cnt_dev, (uint32_t)n_bound,
-                               shift, ws.hist, ws.hist_blocks);
+            hipLaunchKernelGGL((radix_hist_kernel<false, ITEMS>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], cnt_dev,
+                               (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks);
             hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, s, ws.hist, ws.hist_blocks, nblk, dt);
-            hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], val[cur], key[cur ^ 1],
-                               val[cur ^ 1], cnt_dev, (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks, dt, (uint32_t *)nullptr);
+            hipLaunchKernelGGL((radix_scatter_kernel<false, ITEMS, HAS_V2>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], val[cur],
+                               v2i, key[cur ^ 1], val[cur ^ 1], v2o, cnt_dev, (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks,
+                               dt, (uint32_t *)nullptr);
         }
         GSR_HIP(hipGetLastError());
         cur ^= 1;
     }
     *result_buf = cur;
     return GSR_OK;
+}
+
+int launch_radix_sort(uint32_t *const key[2], uint32_t *const val[2], uint32_t *const val2[2], const uint32_t *n_dev,
+                      int64_t n_bound, int passes, bool drop_invalid_first, uint32_t *n_out, int items_per_thread,
+                      const Workspace &ws, int *result_buf, hipStream_t s)
+{
+    *result_buf = 0;
+    if (n_bound <= 0 || passes <= 0) return GSR_OK;
+    if (items_per_thread != 16) { set_error("radix sort: unsupported items_per_thread %d", items_per_thread); return GSR_ERR_BAD_ARG; }
+    return val2 ? sort_passes<16, true>(key, val, val2, n_dev, n_bound, passes, drop_invalid_first, n_out, ws, result_buf, s)
+                : sort_passes<16, false>(key, val, val2, n_dev, n_bound, passes, drop_invalid_first, n_out, ws, result_buf, s);
 }
 
 }  // namespace gsr

@@ -201,3 +201,4 @@ class Rasterizer:
         check(lib.gsr_preprocess(C.byref(sc), C.byref(cam), C.byref(opts), ws.data_ptr(), ws.numel(), C.byref(dbg),
                                  _stream_ptr(dev)))
         return out
+
