@@ -158,6 +158,21 @@ int gsr_sh_to_rgb(int64_t n, const float *means, const float *sh, const float ca
 /* get_covariance_matrix_from_mesh, rasterize.py:89-120: out [n,9] */
 int gsr_cov3d(int64_t n, const float *log_scales, const float *quats, float *cov3d_out, void *stream);
 
+/* project_to_camera_space, rasterize.py:80-86: out[n,3] = means @ w2c[:3,:3] + w2c[3,:3]; w2c [host] row-major 4x4 */
+int gsr_project_to_camera_space(int64_t n, const float *means, const float w2c[16] /* [host] */, float *out, void *stream);
+/* compute_2d_covariance, rasterize.py:201-252: cov3d [n,9], cam_means [n,3] -> cov2d_out [n,4] (2x2 row-major).
+ * tan_fov_*, focal_* are the reference's arguments as given (focals are halved inside, rasterize.py:216). */
+int gsr_compute_2d_covariance(int64_t n, const float *cov3d, const float *cam_means, double tan_fov_x, double tan_fov_y,
+                              double focal_x, double focal_y, const float w2c[16] /* [host] */, float *cov2d_out, void *stream);
+/* compute_covering_bbox, rasterize.py:154-198: screen_means [n,2], cov2d [n,4] -> tile-unit bboxes int64 [n,4] */
+int gsr_compute_covering_bbox(int64_t n, const float *screen_means, const float *cov2d, double width, double height,
+                              int64_t *tile_bboxes_out, void *stream);
+/* rasterize_gaussian, rasterize.py:255-305: blend ONE gaussian in place into screen [W,H,3] / opacity_buffer [W,H]
+ * (the reference's x-major layout).  n = number of gaussians in the per-gaussian arrays (bounds check). */
+int gsr_rasterize_gaussian(int64_t gaussian_index, int64_t n, const int64_t *bboxes, float *screen, const float *screen_means,
+                           const float *sigmas, const float *rgb, float *opacity_buffer, const float *opacity, int32_t width,
+                           int32_t height, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,138 @@
+"""GPU: the reference's module surface (rasterize.py / spherical_harmonics.py / utils.py names) served by libgsr,
+checked against intermediates and frames captured from the real reference (tests/golden)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_frames_close, golden_columns, load_golden, psnr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import gsr_amd
+    from gsr_amd import data_reader, ply, rasterize, spherical_harmonics, synthetic, utils
+
+    ns = types.SimpleNamespace(rasterize=rasterize, sh=spherical_harmonics, utils=utils, ply=ply, colmap=data_reader,
+                               synthetic=synthetic)
+    assert torch.cuda.is_available()
+    return ns
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_constants_match_reference(mods):
+    r = mods.rasterize
+    assert (r.Z_FAR, r.Z_NEAR, r.GAUSSIAN_SPREAD, r.BLOCK_SIZE, r.MAX_GAUSSIAN_DENSITY, r.MIN_ALPHA) == (100.0, 0.01, 3, 16, 0.99, 1 / 255)
+
+
+def test_camera_helpers(mods):
+    g = load_golden("f1_unit.npz")
+    r = mods.rasterize
+    M = r.get_world_to_camera_matrix(torch.tensor(g["qvec"]), torch.tensor(g["tvec"]))
+    assert M.dtype == torch.float32 and np.array_equal(M.numpy(), g["w2c_M"])
+    fov_x = 2 * np.arctan(int(g["cam_width"]) / (2 * float(g["fx_full"])))
+    fov_y = 2 * np.arctan(int(g["cam_height"]) / (2 * float(g["fy_full"])))
+    assert np.array_equal(r.get_projection_matrix(fov_x, fov_y).numpy(), g["proj_P"])
+    q = torch.tensor(np.stack([g["ply_rot_%d" % i] for i in range(4)]))
+    R = r.quaternion_to_rotation_matrix(torch.nn.functional.normalize(q, dim=0))
+    assert tuple(R.shape) == (3, 3, q.shape[1])
+
+
+def test_per_gaussian_helpers_match_reference_intermediates(mods):
+    g = load_golden("f1_unit.npz")
+    r = mods.rasterize
+    cols = golden_columns(g)
+    mesh = types.SimpleNamespace(elements=[cols])
+    means = _dev(np.stack([cols["x"], cols["y"], cols["z"]], 1))
+    w2c = torch.from_numpy(g["w2c_T"])
+    assert np.array_equal(mods.utils.read_color_components(mesh).numpy(), g["sh"])
+    cov3 = r.get_covariance_matrix_from_mesh(mesh)
+    assert _rel(cov3.cpu(), g["cov3d"]) < 1e-6
+    cam = r.project_to_camera_space(means, w2c)
+    assert _rel(cam.cpu(), g["cam_means"]) < 1e-6
+    cov2 = r.compute_2d_covariance(_dev(g["cov3d"]), _dev(g["cam_means"]), float(g["tan_fov_x"]), float(g["tan_fov_y"]), g["focals"], w2c)
+    vis = g["cam_means"][:, 2] >= 0.2
+    assert tuple(cov2.shape) == (len(vis), 2, 2) and _rel(cov2.cpu().numpy()[vis], g["cov2d"][vis]) < 1e-5
+    tb = r.compute_covering_bbox(_dev(g["screen_means"]), _dev(g["cov2d_after_cull"]), int(g["width"]), int(g["height"]))
+    assert tb.dtype == torch.int64 and np.array_equal(tb.cpu().numpy(), g["tile_bboxes"])
+    rgb = mods.sh.sh_to_rgb(means, _dev(g["sh"]), w2c, degree=3)
+    assert _rel(rgb.cpu(), g["rgb"]) < 1e-6
+    rgb0 = mods.sh.sh_to_rgb(means, _dev(g["sh"]), w2c, degree=0)                     # degree 0: 0.5 + C0 * f_dc, clamped
+    np.testing.assert_allclose(rgb0.cpu().numpy(), np.clip(0.5 + 0.28209479177387814 * g["sh"][:, 0, :], 0, 1), atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["f1_unit.npz", "f2_small.npz"])
+def test_reference_loop_through_rasterize_gaussian(mods, name):
+    """The reference's own driver loop (rasterize.py:436-446), with its hot function served by the HIP kernel."""
+    g = load_golden(name)
+    r = mods.rasterize
+    W, H = int(g["width"]), int(g["height"])
+    bboxes, centres, sigmas = _dev(g["pixel_bboxes"]), _dev(g["screen_means"]), _dev(g["sigmas"])
+    rgb, opacity = _dev(g["rgb"]), _dev(g["opacity"])
+    screen = torch.zeros((W, H, 3), device="cuda")
+    trans = torch.ones((W, H), device="cuda")
+    for gi in g["draw_order"]:
+        screen, trans = r.rasterize_gaussian(int(gi), bboxes, screen, centres, sigmas, rgb, trans, opacity)
+    img = screen.transpose(1, 0).cpu().numpy()
+    assert psnr(img, g["image"]) >= 120.0
+    assert_frames_close(img, g["image"])
+
+
+def _write_scene(mods, root, g, scale_factor=2):
+    from PIL import Image
+
+    cols = golden_columns(g)
+    W, H = int(g["width"]), int(g["height"])
+    sparse = os.path.join(root, "scene", "sparse", "0")
+    os.makedirs(sparse)
+    mods.colmap.write_intrinsics_binary(os.path.join(sparse, "cameras.bin"), [mods.colmap.Camera(
+        id=1, model="PINHOLE", width=int(g["cam_width"]), height=int(g["cam_height"]),
+        params=np.array([float(g["fx_full"]), float(g["fy_full"]), int(g["cam_width"]) / 2, int(g["cam_height"]) / 2]))])
+    pose = mods.synthetic.Pose(int(g["image_id"]), g["qvec"], g["tvec"], "view.png")
+    mods.colmap.write_extrinsics_binary(os.path.join(sparse, "images.bin"), [pose])
+    os.makedirs(os.path.join(root, "scene", f"images_{scale_factor}"))
+    Image.new("RGB", (W, H)).save(os.path.join(root, "scene", f"images_{scale_factor}", "view.png"))
+    model = os.path.join(root, "model", "point_cloud", "iteration_30000")
+    os.makedirs(model)
+    mods.ply.write_gaussians_ply(os.path.join(model, "point_cloud.ply"), cols)
+    return os.path.join(root, "scene"), os.path.join(root, "model")
+
+
+def test_run_rasterization_cli_reproduces_the_reference_frame(mods, tmp_path):
+    """Same on-disk inputs, same six options as the reference's command -> the frame its run_rasterization produced."""
+    from click.testing import CliRunner
+
+    g = load_golden("f2_small.npz")
+    scene_dir, model_dir = _write_scene(mods, str(tmp_path), g)
+    out_dir = str(tmp_path / "out")
+    res = CliRunner().invoke(mods.rasterize.run_rasterization, [
+        "--input_dir", scene_dir, "--trained_model_path", model_dir, "--output_path", out_dir,
+        "--scene-index", str(int(g["image_id"])), "--scale-factor", "2"], catch_exceptions=False)
+    assert res.exit_code == 0, res.output
+    img = np.load(os.path.join(out_dir, "render.npy"))
+    assert img.shape == (int(g["height"]), int(g["width"]), 3) and os.path.exists(os.path.join(out_dir, "render.png"))
+    assert psnr(img, g["image"]) >= 100.0
+    assert_frames_close(img, g["image"])
+    # render_scene returns the same frame; a scene index that is not a COLMAP image_id raises KeyError (Q4)
+    assert np.array_equal(mods.rasterize.render_scene(scene_dir, model_dir, int(g["image_id"]), 2).cpu().numpy(), img)
+    with pytest.raises(KeyError):
+        mods.rasterize.render_scene(scene_dir, model_dir, 0, 2)
+
+
+def test_cpu_tensors_are_refused(mods):
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        mods.rasterize.project_to_camera_space(torch.zeros(4, 3), torch.eye(4))
+    with pytest.raises(RuntimeError):
+        mods.sh.sh_to_rgb(torch.zeros(4, 3), torch.zeros(4, 16, 3), torch.eye(4), degree=3)

@@ -97,6 +97,7 @@ class GsrDebugOut(C.Structure):
 EXPORTS = [
     "gsr_version", "gsr_last_error", "gsr_default_options", "gsr_camera_setup", "gsr_workspace_bytes",
     "gsr_preprocess", "gsr_bin_sort", "gsr_blend", "gsr_render_forward", "gsr_read_stats", "gsr_sh_to_rgb", "gsr_cov3d",
+    "gsr_project_to_camera_space", "gsr_compute_2d_covariance", "gsr_compute_covering_bbox", "gsr_rasterize_gaussian",
 ]
 
 
@@ -123,6 +124,11 @@ def _load() -> C.CDLL:
     L.gsr_read_stats.argtypes = [vp, sz, C.POINTER(GsrStats), vp]
     L.gsr_sh_to_rgb.argtypes = [i64, vp, vp, C.POINTER(C.c_float), i32, vp, vp]
     L.gsr_cov3d.argtypes = [i64, vp, vp, vp, vp]
+    f16 = C.POINTER(C.c_float)
+    L.gsr_project_to_camera_space.argtypes = [i64, vp, f16, vp, vp]
+    L.gsr_compute_2d_covariance.argtypes = [i64, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, f16, vp, vp]
+    L.gsr_compute_covering_bbox.argtypes = [i64, vp, vp, C.c_double, C.c_double, vp, vp]
+    L.gsr_rasterize_gaussian.argtypes = [i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     for name in EXPORTS:
         if name not in ("gsr_last_error", "gsr_default_options"):
             getattr(L, name).restype = C.c_int

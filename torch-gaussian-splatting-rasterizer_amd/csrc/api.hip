@@ -292,4 +292,40 @@ int gsr_cov3d(int64_t n, const float *log_scales, const float *quats, float *cov
     return launch_cov3d(n, log_scales, quats, cov3d_out, static_cast<hipStream_t>(stream));
 }
 
+int gsr_project_to_camera_space(int64_t n, const float *means, const float w2c[16], float *out, void *stream)
+{
+    if (n < 0 || !w2c || (n > 0 && (!means || !out))) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
+    return launch_project(n, means, w2c, out, static_cast<hipStream_t>(stream));
+}
+
+int gsr_compute_2d_covariance(int64_t n, const float *cov3d, const float *cam_means, double tan_fov_x, double tan_fov_y,
+                              double focal_x, double focal_y, const float w2c[16], float *cov2d_out, void *stream)
+{
+    if (n < 0 || !w2c || (n > 0 && (!cov3d || !cam_means || !cov2d_out))) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
+    if (reinterpret_cast<uintptr_t>(cov2d_out) % 16 != 0) { set_error("cov2d_out must be 16-byte aligned"); return GSR_ERR_BAD_ARG; }
+    // focals / 2 (rasterize.py:216) and 1.3 * tan_fov (rasterize.py:210-211), formed in float64 like the reference
+    return launch_cov2d(n, cov3d, cam_means, w2c, (float)(focal_x / 2.0), (float)(focal_y / 2.0), (float)(1.3 * tan_fov_x),
+                        (float)(1.3 * tan_fov_y), cov2d_out, static_cast<hipStream_t>(stream));
+}
+
+int gsr_compute_covering_bbox(int64_t n, const float *screen_means, const float *cov2d, double width, double height,
+                              int64_t *tile_bboxes_out, void *stream)
+{
+    if (n < 0 || (n > 0 && (!screen_means || !cov2d || !tile_bboxes_out))) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
+    if (reinterpret_cast<uintptr_t>(cov2d) % 16 != 0) { set_error("cov2d must be 16-byte aligned"); return GSR_ERR_BAD_ARG; }
+    return launch_bbox(n, screen_means, cov2d, (float)width, (float)height, tile_bboxes_out, static_cast<hipStream_t>(stream));
+}
+
+int gsr_rasterize_gaussian(int64_t gaussian_index, int64_t n, const int64_t *bboxes, float *screen, const float *screen_means,
+                           const float *sigmas, const float *rgb, float *opacity_buffer, const float *opacity, int32_t width,
+                           int32_t height, void *stream)
+{
+    if (!bboxes || !screen || !screen_means || !sigmas || !rgb || !opacity_buffer || !opacity || width <= 0 || height <= 0) {
+        set_error("bad argument"); return GSR_ERR_BAD_ARG;
+    }
+    if (gaussian_index < 0 || gaussian_index >= n) { set_error("gaussian_index %lld out of range", (long long)gaussian_index); return GSR_ERR_BAD_ARG; }
+    return launch_rasterize_gaussian(gaussian_index, bboxes, screen, screen_means, sigmas, rgb, opacity_buffer, opacity, width, height,
+                                     static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

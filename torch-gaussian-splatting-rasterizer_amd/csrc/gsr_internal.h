@@ -76,6 +76,12 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
                       const GsrDebugOut *dbg, hipStream_t s);
 int launch_sh_to_rgb(int64_t n, const float *means, const float *sh, const float cc[3], int degree, float *rgb, hipStream_t s);
 int launch_cov3d(int64_t n, const float *log_scales, const float *quats, float *out, hipStream_t s);
+int launch_project(int64_t n, const float *means, const float w2c[16], float *out, hipStream_t s);
+int launch_cov2d(int64_t n, const float *cov3d, const float *cam_means, const float w2c[16], float fx, float fy, float limx, float limy,
+                 float *out, hipStream_t s);
+int launch_bbox(int64_t n, const float *screen_means, const float *cov2d, float W, float H, int64_t *out, hipStream_t s);
+int launch_rasterize_gaussian(int64_t g, const int64_t *bboxes, float *screen, const float *screen_means, const float *sigmas,
+                              const float *rgb, float *opacity_buffer, const float *opacity, int W, int H, hipStream_t s);
 
 // LSD radix sort of (key,val) u32 pairs, 8 bits per pass over bits [0, 8*passes).
 // n_dev: device pointer to the element count (may be nullptr -> n_bound is the count).

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <algorithm>
 #include "gsr_internal.h"
+#include "gauss_math.h"
 
 namespace gsr {
 
@@ -21,88 +22,6 @@ struct Cam {
     float fx, fy, limx, limy;
     int W, H;
 };
-
-// rasterize.py:41-56 on fp32 inputs
-__device__ __forceinline__ void quat_to_rot(float w, float x, float y, float z, float R[3][3])
-{
-    R[0][0] = 1.0f - 2.0f * (y * y) - 2.0f * (z * z); R[0][1] = 2.0f * x * y - 2.0f * z * w;           R[0][2] = 2.0f * x * z + 2.0f * y * w;
-    R[1][0] = 2.0f * x * y + 2.0f * z * w;           R[1][1] = 1.0f - 2.0f * (x * x) - 2.0f * (z * z); R[1][2] = 2.0f * y * z - 2.0f * x * w;
-    R[2][0] = 2.0f * x * z - 2.0f * y * w;           R[2][1] = 2.0f * y * z + 2.0f * x * w;           R[2][2] = 1.0f - 2.0f * (x * x) - 2.0f * (y * y);
-}
-
-// get_covariance_matrix_from_mesh, rasterize.py:89-120
-__device__ __forceinline__ void cov3d_of(const float ls[3], const float4 q, float cov[3][3])
-{
-    const float s[3] = {expf(ls[0]), expf(ls[1]), expf(ls[2])};
-    float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-    nrm = nrm < 1e-12f ? 1e-12f : nrm;  // F.normalize eps, :112
-    float R[3][3], M[3][3];
-    quat_to_rot(q.x / nrm, q.y / nrm, q.z / nrm, q.w / nrm, R);
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) M[i][j] = R[i][j] * s[j];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) cov[i][j] = M[i][0] * M[j][0] + M[i][1] * M[j][1] + M[i][2] * M[j][2];
-}
-
-// sh_to_rgb, spherical_harmonics.py:27-73; sh = 48 floats [16][3] of one gaussian, already in registers.
-__device__ __forceinline__ void sh_eval(const float p[3], const float *sh, const float cc[3], int degree, float rgb[3])
-{
-    const float d0 = p[0] - cc[0], d1 = p[1] - cc[1], d2 = p[2] - cc[2];
-    const float n = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
-    const float x = d0 / n, y = d1 / n, z = d2 / n;
-    const float c0 = 0.28209479177387814f, c1 = 0.4886025119029199f, nc1 = -0.4886025119029199f;
-    const float k20 = 1.0925484305920792f, k21 = -1.0925484305920792f, k22 = 0.31539156525252005f,
-                k23 = -1.0925484305920792f, k24 = 0.5462742152960396f;
-    const float k30 = -0.5900435899266435f, k31 = 2.890611442640554f, k32 = -0.4570457994644658f,
-                k33 = 0.3731763325901154f, k34 = -0.4570457994644658f, k35 = 1.445305721320277f,
-                k36 = -0.5900435899266435f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-#define SHC(k) sh[(k) * 3 + c]
-        float col = SHC(0) * c0;
-        if (degree > 0) {  // :45-46
-            col = col + (((nc1 * y) * SHC(1) + (c1 * z) * SHC(2)) - (c1 * x) * SHC(3));
-            if (degree > 1) {  // :48-55
-                const float t4 = ((k20 * x) * y) * SHC(4);
-                const float t5 = ((k21 * y) * z) * SHC(5);
-                const float t6 = (k22 * (((2.0f * z) * z - x * x) - y * y)) * SHC(6);
-                const float t7 = ((k23 * x) * z) * SHC(7);
-                const float t8 = (k24 * (x * x - y * y)) * SHC(8);
-                col = col + ((((t4 + t5) + t6) + t7) + t8);
-                if (degree > 2) {  // :56-65
-                    const float t9 = ((k30 * y) * ((3.0f * x) * x - y * y)) * SHC(9);
-                    const float t10 = (((k31 * x) * y) * z) * SHC(10);
-                    const float t11 = ((k32 * y) * (((4.0f * z) * z - x * x) - y * y)) * SHC(11);
-                    const float t12 = ((k33 * z) * (((2.0f * z) * z - (3.0f * x) * x) - (3.0f * y) * y)) * SHC(12);
-                    const float t13 = ((k34 * x) * (((4.0f * z) * z - x * x) - y * y)) * SHC(13);
-                    const float t14 = ((k35 * z) * (x * x - y * y)) * SHC(14);
-                    const float t15 = ((k36 * x) * (x * x - (3.0f * y) * y)) * SHC(15);
-                    col = col + ((((((t9 + t10) + t11) + t12) + t13) + t14) + t15);
-                }
-            }
-        }
-#undef SHC
-        col = col + 0.5f;                                     // :69
-        rgb[c] = col < 0.0f ? 0.0f : (col > 1.0f ? 1.0f : col);  // :71 (Q7)
-    }
-}
-
-__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-__device__ __forceinline__ void load_sh48(const float *sh, int64_t i, float out[48])
-{
-    const float4 *p = reinterpret_cast<const float4 *>(sh + 48 * i);  // 192-B rows are 16-B aligned
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        const float4 v = p[k];
-        out[4 * k] = v.x; out[4 * k + 1] = v.y; out[4 * k + 2] = v.z; out[4 * k + 3] = v.w;
-    }
-}
 
 template <bool DEBUG>
 __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, GaussRec *__restrict__ rec,
@@ -136,32 +55,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
     cov3d_of(ls, q, C3);
 
     // compute_2d_covariance, :201-252
-    const float tz = cm[2];
-    const float txtz = cm[0] / tz, tytz = cm[1] / tz;
-    const float tx = fminf(cam.limx, fmaxf(-cam.limx, txtz)) * tz;
-    const float ty = fminf(cam.limy, fmaxf(-cam.limy, tytz)) * tz;
-    float J[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    J[0][0] = cam.fx / tz;
-    J[0][2] = -(cam.fx * tx) / (tz * tz);
-    J[1][1] = cam.fy / tz;
-    J[1][2] = -(cam.fy * ty) / (tz * tz);
-    float T[3][3], TV[3][3], PC[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) T[r][c] = (V[4 * c + 0] * J[r][0] + V[4 * c + 1] * J[r][1]) + V[4 * c + 2] * J[r][2];  // :230-232
-    const float vrk[3][3] = {{C3[0][0], C3[0][1], C3[0][2]}, {C3[0][1], C3[1][1], C3[1][2]}, {C3[0][2], C3[1][2], C3[2][2]}};  // :234-243
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) TV[r][c] = (T[r][0] * vrk[0][c] + T[r][1] * vrk[1][c]) + T[r][2] * vrk[2][c];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) PC[r][c] = (TV[r][0] * T[c][0] + TV[r][1] * T[c][1]) + TV[r][2] * T[c][2];  // :245
-    PC[0][0] += GSR_LOWPASS;  // :249
-    PC[1][1] += GSR_LOWPASS;  // :250
-    float a = PC[0][0], b01 = PC[0][1], b10 = PC[1][0], c = PC[1][1];
+    float c2[4];
+    ewa_cov2d(V, C3, cm, cam.fx, cam.fy, cam.limx, cam.limy, c2);
+    float a = c2[0], b01 = c2[1], b10 = c2[2], c = c2[3];
     if (DEBUG && dbg.cov2d) { dbg.cov2d[4 * i] = a; dbg.cov2d[4 * i + 1] = b01; dbg.cov2d[4 * i + 2] = b10; dbg.cov2d[4 * i + 3] = c; }
     if (culled) a = b01 = b10 = c = 0.0f;  // :388
 
@@ -170,15 +66,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
     const float mx = ((ndc_x + 1.0f) * Wf - 1.0f) / 2.0f, my = ((ndc_y + 1.0f) * Hf - 1.0f) / 2.0f;
 
     // compute_covering_bbox, :154-198
-    const float det = a * c - b10 * b01;
-    const float trace = a + c;
-    const float disc = sqrtf(fmaxf((trace * trace) / 4.0f - det, GSR_EIG_FLOOR));
-    const float l1 = trace / 2.0f + disc, l2 = trace / 2.0f - disc;
-    const float spread = ceilf(GSR_GAUSSIAN_SPREAD * sqrtf(fmaxf(l1, l2)));
-    const float tb0 = floorf(clampf((mx - spread) / 16.0f, 0.0f, Wf - 1.0f));
-    const float tb1 = floorf(clampf((my - spread) / 16.0f, 0.0f, Hf - 1.0f));
-    const float tb2 = floorf(clampf((mx + (spread + 16.0f - 1.0f)) / 16.0f, 0.0f, Wf - 1.0f));
-    const float tb3 = floorf(clampf((my + (spread + 16.0f - 1.0f)) / 16.0f, 0.0f, Hf - 1.0f));
+    float tb[4], det, spread;
+    covering_bbox(mx, my, a, b01, b10, c, Wf, Hf, tb, &det, &spread);
+    const float tb0 = tb[0], tb1 = tb[1], tb2 = tb[2], tb3 = tb[3];
 
     // conic, :395-411
     const float det_inv = det == 0.0f ? 0.0f : 1.0f / det;
@@ -294,52 +184,6 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
         hipLaunchKernelGGL(preprocess_kernel<false>, dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat, opts.no_footprint_cull, ws.rec,
                            ws.rect, ws.rect8[0], ws.key[0], ws.val[0], d);
     }
-    GSR_HIP(hipGetLastError());
-    return GSR_OK;
-}
-
-// ---- stand-alone helpers ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sh_to_rgb_kernel(int64_t n, const float *__restrict__ means, const float *__restrict__ sh,
-                                                        float cx, float cy, float cz, int degree, float *__restrict__ out)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
-    const float cc[3] = {cx, cy, cz};
-    float c[48], rgb[3];
-    load_sh48(sh, i, c);
-    sh_eval(p, c, cc, degree, rgb);
-    out[3 * i] = rgb[0]; out[3 * i + 1] = rgb[1]; out[3 * i + 2] = rgb[2];
-}
-
-int launch_sh_to_rgb(int64_t n, const float *means, const float *sh, const float cc[3], int degree, float *rgb, hipStream_t s)
-{
-    if (n <= 0) return GSR_OK;
-    hipLaunchKernelGGL(sh_to_rgb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, means, sh, cc[0], cc[1], cc[2],
-                       degree, rgb);
-    GSR_HIP(hipGetLastError());
-    return GSR_OK;
-}
-
-__global__ __launch_bounds__(256) void cov3d_kernel(int64_t n, const float *__restrict__ log_scales, const float *__restrict__ quats,
-                                                    float *__restrict__ out)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float ls[3] = {log_scales[3 * i], log_scales[3 * i + 1], log_scales[3 * i + 2]};
-    const float4 q = reinterpret_cast<const float4 *>(quats)[i];
-    float C3[3][3];
-    cov3d_of(ls, q, C3);
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) out[9 * i + 3 * r + c] = C3[r][c];
-}
-
-int launch_cov3d(int64_t n, const float *log_scales, const float *quats, float *out, hipStream_t s)
-{
-    if (n <= 0) return GSR_OK;
-    hipLaunchKernelGGL(cov3d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, log_scales, quats, out);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }
