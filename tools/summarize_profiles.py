@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_* directory (rocprofv3 csv output) into the small, judged files under profiles/.
+
+usage: tools/summarize_profiles.py gpurun_out/prof_r1 profiles/r1
+writes <out>_kernel_stats.csv (the --stats summary, verbatim), <out>_frame_timeline.txt, <out>_pmc.json and
+updates profiles/pmc_traffic.json (per-launch HBM traffic of the blend kernel, read by bench.py).
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE
+tallies 128-B requests at 64 B, i.e. reads come out at one half for wide coalesced streams — the corrected figure
+doubles it; WRITE_SIZE is exact.  Both raw and corrected values are kept.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+
+def main():
+    src, out = sys.argv[1], sys.argv[2]
+    os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+    shutil.copy(os.path.join(src, "trace_kernel_stats.csv"), out + "_kernel_stats.csv")
+    tl = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "frame_timeline.py"),
+                         os.path.join(src, "trace_kernel_trace.csv")], capture_output=True, text=True).stdout
+    open(out + "_frame_timeline.txt", "w").write(tl)
+    pmc = {}
+    for f in sorted(glob.glob(os.path.join(src, "pmc_*_counter_collection.csv"))):
+        per = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            kern = "blend_kernel" if "blend_kernel" in r["Kernel_Name"] else ("preprocess_kernel" if "preprocess_kernel" in r["Kernel_Name"] else r["Kernel_Name"][:40])
+            per[kern][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for kern, cs in per.items():
+            for c, v in cs.items():
+                steady = v[len(v) // 2:]  # drop warm-up launches
+                pmc.setdefault(kern, {})[c] = {"per_launch_mean": sum(steady) / len(steady), "launches": len(v)}
+    derived = {}
+    for kern, cs in pmc.items():
+        d = {}
+        if "FETCH_SIZE" in cs:
+            d["fetch_bytes_raw"] = cs["FETCH_SIZE"]["per_launch_mean"] * 1024
+            d["fetch_bytes_corrected_x2"] = 2 * d["fetch_bytes_raw"]
+        if "WRITE_SIZE" in cs:
+            d["write_bytes"] = cs["WRITE_SIZE"]["per_launch_mean"] * 1024
+        if "fetch_bytes_raw" in d and "write_bytes" in d:
+            d["hbm_bytes_per_launch"] = d["fetch_bytes_corrected_x2"] + d["write_bytes"]
+        derived[kern] = d
+    json.dump({"counters": pmc, "derived": derived}, open(out + "_pmc.json", "w"), indent=1)
+    tfile = os.path.join(os.path.dirname(out) or ".", "pmc_traffic.json")
+    traffic = json.load(open(tfile)) if os.path.exists(tfile) else {}
+    if "blend_kernel" in derived and "hbm_bytes_per_launch" in derived["blend_kernel"]:
+        traffic.setdefault("garden", {})["blend_kernel_bytes_per_launch"] = derived["blend_kernel"]["hbm_bytes_per_launch"]
+        traffic["garden"]["source"] = os.path.basename(out) + "_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+    json.dump(traffic, open(tfile, "w"), indent=1)
+    print(tl)
+    print(json.dumps(derived, indent=1))
+
+
+if __name__ == "__main__":
+    main()
