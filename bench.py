@@ -34,7 +34,8 @@ import torch
 WORKLOADS = {
     # name: (generator, n, seed, W, H, description)
     "garden": ("mip360_like", 5_834_784, 360, 1920, 1080, "synthetic stand-in for MipNeRF-360 garden (configs[1])"),
-    "bicycle": ("mip360_like", 6_131_954, 361, 1920, 1080, "synthetic stand-in for MipNeRF-360 bicycle (configs[2], fp32)"),
+    "bicycle": ("mip360_like", 6_131_954, 361, 1920, 1080, "synthetic stand-in for MipNeRF-360 bicycle (configs[2]): fp16 SH storage; "
+                "blend accumulators stay fp32 (bf16 accumulators measure 41 dB < the 50 dB bar, SURVEY.md §7)"),
     "box4k": ("uniform_box", 20_000_000, 20, 3840, 2160, "20M uniform gaussians at 4K (configs[4])"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
@@ -60,6 +61,7 @@ def parse():
     ap.add_argument("--workload", default="garden", choices=sorted(WORKLOADS))
     ap.add_argument("--n", type=int, default=0, help="override the gaussian count (0 = the workload's)")
     ap.add_argument("--early-out-T", type=float, default=0.0)
+    ap.add_argument("--sh-half", action="store_true", help="store SH coefficients as fp16 (implied by --workload bicycle)")
     ap.add_argument("--camera", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
@@ -105,7 +107,8 @@ def main():
     cols, cam_args, n, W, H, desc = build_workload(args)
     packed = utils.pack_gaussians(cols)
     del cols
-    scene = renderer.GaussianScene.from_packed(packed, device=dev)
+    sh_half = args.sh_half or args.workload == "bicycle"
+    scene = renderer.GaussianScene.from_packed(packed, device=dev, sh_half=sh_half)
     cam = renderer.make_camera(*cam_args)
     plan = gdist.TileRowPlan(H, W, world)
     fg = gdist.FrameGather(plan, rank, dev)
@@ -157,7 +160,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "gaussians": n, "width": W, "height": H, "camera": args.camera,
                        "sharding": f"tile rows interleaved over {world} GPU(s), RCCL gather to rank 0" if world > 1 else "none",
-                       "reference_compat": True, "early_out_T": args.early_out_T},
+                       "reference_compat": True, "early_out_T": args.early_out_T, "sh_storage": "f16" if sh_half else "f32"},
             "stats_rank0_shard": shard_stats,
         }
 
@@ -191,7 +194,7 @@ def main():
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         E, P, V = st["n_pairs"], W * H, st["n_visible"]
         blend_bytes = 40.0 * E + 12.0 * P + 8.0 * tiles
-        pre_bytes = 236.0 * n + 64.0 * V
+        pre_bytes = (140.0 if sh_half else 236.0) * n + 64.0 * V
         achieved = blend_bytes / (stage[2] * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")

@@ -50,9 +50,10 @@ typedef struct GsrScene {
     const float *log_scales;    /* [n,3]  scale_0..2, BEFORE exp (rasterize.py:97) */
     const float *quats;         /* [n,4]  rot_0..3 = (w,x,y,z), un-normalised (rasterize.py:99-112) */
     const float *opacity_logit; /* [n]    BEFORE sigmoid (rasterize.py:358) */
-    const float *sh;            /* [n,16,3] sh[i][k][c], k=0 is f_dc (utils.py:21-31) */
+    const void *sh;             /* [n,16,3] sh[i][k][c], k=0 is f_dc (utils.py:21-31); fp32, or IEEE fp16 if sh_dtype = 1 */
     int32_t sh_degree;          /* 0..3; the reference always evaluates 3 (rasterize.py:368) */
-    int32_t _pad;
+    int32_t sh_dtype;           /* 0 = float32 (the reference's type), 1 = float16 storage (evaluated in fp32; halves the
+                                   192-B/gaussian stream that dominates stage 1; ~91 dB vs fp32 coefficients) */
 } GsrScene;
 
 /* One view.  Filled by gsr_camera_setup() or by hand.  All matrices are in the reference's
@@ -146,6 +147,14 @@ int gsr_blend(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t m
 /* Stages 1-3 back to back: the whole render call of rasterize.py:354-446. */
 int gsr_render_forward(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,
                        void *workspace, size_t workspace_bytes, float *out_image, float *out_final_T, void *stream);
+
+/* Several views of ONE resident scene, enqueued back to back on the stream with one workspace (the reference renders
+ * one view per process, rasterize.py:315-329).  cams[n_cams] [host] must share width/height; frame i goes to
+ * out_images + i * frame_stride (floats).  Counters afterwards describe the LAST view; an overflow in any view is
+ * sticky in them. */
+int gsr_render_batch(const GsrScene *scene, const GsrCamera *cams /* [host] */, int32_t n_cams, const GsrOptions *opts,
+                     int64_t max_pairs, void *workspace, size_t workspace_bytes, float *out_images, int64_t frame_stride,
+                     void *stream);
 
 /* Copies the frame counters to host memory and waits for the stream.  Returns GSR_ERR_PAIR_OVERFLOW if the
  * frame overflowed max_pairs. */

@@ -88,6 +88,70 @@ def test_frame_matches_reference_and_oracle(G, name, prefix):
     assert R.last_stats["n_visible"] <= drawn                    # footprint culling only ever drops gaussians
 
 
+@pytest.mark.parametrize("degree", [0, 1, 2, 3])
+def test_sh_degrees_vs_oracle(G, degree):
+    g = load_golden("f2_small.npz")
+    cols = golden_columns(g)
+    cam, ocam = _cams(G, g)
+    img = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols, sh_degree=degree)).render(cam).cpu().numpy()
+    oimg, _ = G.orc.render(G.utils.pack_gaussians(cols), ocam, sh_degree=degree)
+    assert_frames_close(img, oimg)
+    if degree == 3:
+        assert psnr(img, g["image"]) >= 100.0
+
+
+def test_fp16_sh_storage(G):
+    """BASELINE configs[2]: SH coefficients stored as fp16 (evaluated in fp32).  == rendering the fp16-rounded
+    coefficients exactly, and >= 75 dB from the fp32-coefficient frame (SURVEY measured 91 dB on its scene)."""
+    cols, cam, ocam = _medium(G)
+    full = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols)).render(cam).cpu().numpy()
+    half = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols, sh_half=True)).render(cam).cpu().numpy()
+    packed = G.utils.pack_gaussians(cols)
+    packed["sh"] = packed["sh"].astype(np.float16).astype(np.float32)
+    rounded = G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(packed)).render(cam).cpu().numpy()
+    assert np.array_equal(half, rounded)
+    assert psnr(half, full) >= 75.0, psnr(half, full)
+
+
+def test_degenerate_inputs(G):
+    """n = 0, a frame smaller than one tile, everything culled, a single gaussian."""
+    p = G.synthetic.look_at_pose((0, -4, 0.5), (0, 0, 0), 1, "x.png")
+    for (W, H) in ((10, 7), (16, 16), (33, 17)):
+        fx = G.synthetic.pinhole_focal(W)
+        args = (p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H)
+        cam, ocam = G.renderer.make_camera(*args), G.orc.camera(*args)
+        for n in (0, 1, 300):
+            cols = G.synthetic.mip360_like(max(n, 1), 3)
+            for i in range(3):
+                cols[f"scale_{i}"] = (cols[f"scale_{i}"] + np.float32(3.0)).astype(np.float32)
+            cols = {k: v[:n] for k, v in cols.items()}
+            packed = G.utils.pack_gaussians(cols)
+            R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(packed))
+            img, T = R.render(cam, return_T=True)
+            oimg, oT, _ = G.orc.render(packed, ocam, want_T=True) if n else (np.zeros((H, W, 3), np.float32), np.ones((H, W), np.float32), 0)
+            assert_frames_close(img.cpu().numpy(), oimg)
+            assert np.abs(T.cpu().numpy() - oT).max() < 1e-5
+    # every gaussian behind the camera
+    cols = G.synthetic.mip360_like(500, 4)
+    cols["y"] = (cols["y"] - np.float32(100.0)).astype(np.float32)  # camera at y = -4 looks along +y
+    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
+    assert not R.render(cam).any() and R.last_stats["n_visible"] == 0 and R.last_stats["n_pairs"] == 0
+
+
+def test_multi_camera_batch(G):
+    """several views of the resident scene in one call == the views rendered one by one."""
+    cols, cam0, _ = _medium(G, n=60_000)
+    W, H = cam0.width, cam0.height
+    fx = G.synthetic.pinhole_focal(W)
+    cams = [G.renderer.make_camera(p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H) for p in G.synthetic.ring_cameras(25)[::5]]
+    scene = G.renderer.GaussianScene.from_columns(cols)
+    singles = torch.stack([G.renderer.Rasterizer(scene).render(c) for c in cams])
+    R = G.renderer.Rasterizer(scene, max_pairs=2048)               # too small: an overflow in ANY view must be caught
+    batch = R.render_batch(cams)
+    assert R.max_pairs > 2048 and torch.equal(batch, singles)
+    assert not torch.equal(singles[0], singles[1])
+
+
 def test_reference_screen_layout(G):
     g = load_golden("f2_small.npz")
     cam, _ = _cams(G, g)

@@ -104,3 +104,28 @@ def test_synthetic_generators_are_deterministic():
     assert np.abs(c["x"]).max() <= 10 and c["x"].dtype == np.float32
     for p in synthetic.ring_cameras(5) + [synthetic.box_camera()]:
         assert abs(np.linalg.norm(p.qvec) - 1) < 1e-12
+
+
+def test_look_at_pose_geometry():
+    """COLMAP convention x_cam = R(qvec) x_world + t: the eye maps to the origin, the target lies on +z,
+    world-up maps to -y (y points down)."""
+    from gsr_amd import synthetic
+
+    def rot(q):
+        w, x, y, z = q
+        return np.array([[1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * z * w, 2 * x * z + 2 * y * w],
+                         [2 * x * y + 2 * z * w, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * x * w],
+                         [2 * x * z - 2 * y * w, 2 * y * z + 2 * x * w, 1 - 2 * x * x - 2 * y * y]])
+
+    for eye, target in (((4.0, 0.0, 1.0), (0, 0, 0)), ((0.5, -3.0, 1.0), (0.0, 0.0, 3.0)), ((-2.0, 2.5, 0.3), (1.0, 0.0, 0.2))):
+        p = synthetic.look_at_pose(eye, target, 1, "a.png")
+        R = rot(p.qvec)
+        np.testing.assert_allclose(R @ np.array(eye) + p.tvec, 0, atol=1e-12)
+        t_cam = R @ np.array(target, float) + p.tvec
+        np.testing.assert_allclose(t_cam[:2], 0, atol=1e-12)
+        assert t_cam[2] > 0
+        assert (R @ np.array([0.0, 0.0, 1.0]))[1] < 0
+    for p in synthetic.ring_cameras(8):
+        c = rot(p.qvec) @ np.zeros(3) + p.tvec                     # the origin, seen from the ring camera
+        np.testing.assert_allclose(c[:2], 0, atol=1e-9)
+        assert abs(c[2] - np.hypot(4.0, 1.0)) < 1e-9

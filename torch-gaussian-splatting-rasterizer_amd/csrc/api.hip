@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstddef>
 #include <cstring>
 
 #include "gsr_internal.h"
@@ -190,14 +191,24 @@ static int check_scene(const GsrScene *sc)
         set_error("null scene array"); return GSR_ERR_BAD_ARG;
     }
     if (sc->sh_degree < 0 || sc->sh_degree > 3) { set_error("sh_degree %d not in 0..3", sc->sh_degree); return GSR_ERR_BAD_ARG; }
+    if (sc->sh_dtype != 0 && sc->sh_dtype != 1) { set_error("sh_dtype %d: 0 (float32) or 1 (float16)", sc->sh_dtype); return GSR_ERR_BAD_ARG; }
     if (reinterpret_cast<uintptr_t>(sc->sh) % 16 != 0 || reinterpret_cast<uintptr_t>(sc->quats) % 16 != 0) {
         set_error("sh and quats must be 16-byte aligned"); return GSR_ERR_BAD_ARG;
     }
     return GSR_OK;
 }
 
+static int preprocess_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
+                           size_t workspace_bytes, const GsrDebugOut *debug, void *stream, bool keep_batch_words);
+
 int gsr_preprocess(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
                    size_t workspace_bytes, const GsrDebugOut *debug, void *stream)
+{
+    return preprocess_impl(scene, cam, opts, workspace, workspace_bytes, debug, stream, false);
+}
+
+static int preprocess_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
+                           size_t workspace_bytes, const GsrDebugOut *debug, void *stream, bool keep_batch_words)
 {
     int rc = check_scene(scene);
     if (rc) return rc;
@@ -207,7 +218,7 @@ int gsr_preprocess(const GsrScene *scene, const GsrCamera *cam, const GsrOptions
     rc = check_frame(scene->n, cam, opts, 0, workspace, workspace_bytes, &ws);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    GSR_HIP(hipMemsetAsync(ws.ctrl, 0, sizeof(FrameCtrl), s));
+    GSR_HIP(hipMemsetAsync(ws.ctrl, 0, keep_batch_words ? offsetof(FrameCtrl, batch_overflow) : sizeof(FrameCtrl), s));
     return launch_preprocess(*scene, *cam, *opts, ws, debug, s);
 }
 
@@ -245,8 +256,19 @@ int gsr_blend(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t m
     return launch_blend(*cam, *opts, ws, max_pairs > 0 ? pbuf : 0, out_image, out_final_T, static_cast<hipStream_t>(stream));
 }
 
+static int render_forward_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,
+                               void *workspace, size_t workspace_bytes, float *out_image, float *out_final_T, void *stream,
+                               bool keep_batch_words);
+
 int gsr_render_forward(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,
                        void *workspace, size_t workspace_bytes, float *out_image, float *out_final_T, void *stream)
+{
+    return render_forward_impl(scene, cam, opts, max_pairs, workspace, workspace_bytes, out_image, out_final_T, stream, false);
+}
+
+static int render_forward_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,
+                               void *workspace, size_t workspace_bytes, float *out_image, float *out_final_T, void *stream,
+                               bool keep_batch_words)
 {
     int rc = check_scene(scene);
     if (rc) return rc;
@@ -254,11 +276,28 @@ int gsr_render_forward(const GsrScene *scene, const GsrCamera *cam, const GsrOpt
     Workspace ws;
     rc = check_frame(scene->n, cam, opts, max_pairs, workspace, workspace_bytes, &ws);
     if (rc) return rc;
-    rc = gsr_preprocess(scene, cam, opts, workspace, workspace_bytes, nullptr, stream);
+    rc = preprocess_impl(scene, cam, opts, workspace, workspace_bytes, nullptr, stream, keep_batch_words);
     if (rc) return rc;
     rc = gsr_bin_sort(scene->n, cam, opts, max_pairs, workspace, workspace_bytes, stream);
     if (rc) return rc;
     return gsr_blend(scene->n, cam, opts, max_pairs, workspace, workspace_bytes, out_image, out_final_T, stream);
+}
+
+int gsr_render_batch(const GsrScene *scene, const GsrCamera *cams, int32_t n_cams, const GsrOptions *opts, int64_t max_pairs,
+                     void *workspace, size_t workspace_bytes, float *out_images, int64_t frame_stride, void *stream)
+{
+    if (!cams || n_cams < 0 || !out_images) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
+    for (int32_t i = 0; i < n_cams; ++i) {
+        if (cams[i].width != cams[0].width || cams[i].height != cams[0].height) { set_error("views of a batch must share one frame size"); return GSR_ERR_BAD_ARG; }
+        if (frame_stride < (int64_t)cams[i].width * cams[i].height * 3) { set_error("frame_stride smaller than a frame"); return GSR_ERR_BAD_ARG; }
+    }
+    for (int32_t i = 0; i < n_cams; ++i) {
+        // view 0 clears the whole control block, later views keep the batch-sticky overflow words
+        int rc = render_forward_impl(scene, &cams[i], opts, max_pairs, workspace, workspace_bytes,
+                                     out_images + (size_t)i * frame_stride, nullptr, stream, i > 0);
+        if (rc) return rc;
+    }
+    return GSR_OK;
 }
 
 int gsr_read_stats(const void *workspace, size_t workspace_bytes, GsrStats *out, void *stream)

@@ -123,8 +123,12 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(uint32_t *__restrict__ 
     }
     if (tid == 0) {
         const unsigned long long D = grand;
-        ctrl->n_pairs_bbox = D > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)D;
-        ctrl->overflow = D > (unsigned long long)max_pairs ? 1u : 0u;
+        const uint32_t Dc = D > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)D;
+        // batch_overflow / batch_need survive the per-frame clear inside gsr_render_batch: an overflow in any view of
+        // a batch stays visible in the counters of the last one, together with the largest D of the batch
+        if (D > (unsigned long long)max_pairs) { ctrl->batch_overflow = 1u; ctrl->batch_need = max(ctrl->batch_need, Dc); }
+        ctrl->overflow = ctrl->batch_overflow;
+        ctrl->n_pairs_bbox = ctrl->batch_overflow ? max(ctrl->batch_need, Dc) : Dc;
         ctrl->n_slots = D > (unsigned long long)max_pairs ? max_pairs : (uint32_t)D;
     }
 }

@@ -3,6 +3,7 @@
 // this header are built with -ffp-contract=off.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include "../../include/gsr.h"
 
 namespace gsr {
@@ -78,6 +79,22 @@ __device__ __forceinline__ void sh_eval(const float p[3], const float *sh, const
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// fp16 storage: 96-B rows, six 16-B loads, widened to fp32 before evaluation
+__device__ __forceinline__ void load_sh48_f16(const void *sh, int64_t i, float out[48])
+{
+    const uint4 *p = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sh) + 96 * i);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const uint4 v = p[k];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            out[8 * k + 2 * j] = __half2float(__ushort_as_half((unsigned short)(w[j] & 0xFFFFu)));
+            out[8 * k + 2 * j + 1] = __half2float(__ushort_as_half((unsigned short)(w[j] >> 16)));
+        }
+    }
+}
 
 __device__ __forceinline__ void load_sh48(const float *sh, int64_t i, float out[48])
 {

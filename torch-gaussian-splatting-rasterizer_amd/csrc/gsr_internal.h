@@ -21,6 +21,8 @@ struct FrameCtrl {
     uint32_t n_slots;       // min(D, max_pairs): pair slots written by the emit kernel
     unsigned long long wave_entries;  // (quadrant, entry) pairs evaluated by the blend
     uint32_t digit_tot[256]; // per-digit totals of the radix pass in flight
+    uint32_t batch_overflow; // sticky across the views of gsr_render_batch (not cleared per frame)
+    uint32_t batch_need;     // largest D seen in the batch
 };
 
 // Per-gaussian record consumed by pair emission and the blend (48 B, three 16-B loads):

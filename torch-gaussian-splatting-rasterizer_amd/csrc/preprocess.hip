@@ -23,7 +23,7 @@ struct Cam {
     int W, H;
 };
 
-template <bool DEBUG>
+template <bool DEBUG, bool SH16>
 __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, GaussRec *__restrict__ rec,
                                                          ushort4 *__restrict__ rect, uint32_t *__restrict__ rect8, uint32_t *__restrict__ depth_key,
                                                          uint32_t *__restrict__ ident, GsrDebugOut dbg)
@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
     float rgb[3] = {0.f, 0.f, 0.f};
     if (visible || (DEBUG && dbg.rgb)) {
         float sh[48];
-        load_sh48(sc.sh, i, sh);
+        if (SH16) load_sh48_f16(sc.sh, i, sh);
+        else load_sh48(reinterpret_cast<const float *>(sc.sh), i, sh);
         sh_eval(p, sh, cam.cc, sc.sh_degree, rgb);  // :368
         if (DEBUG && dbg.rgb) { dbg.rgb[3 * i] = rgb[0]; dbg.rgb[3 * i + 1] = rgb[1]; dbg.rgb[3 * i + 2] = rgb[2]; }
     }
@@ -176,14 +177,14 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
     const Cam k = make_cam(cam);
     GsrDebugOut d;
     memset(&d, 0, sizeof d);
-    if (dbg) {
-        d = *dbg;
-        hipLaunchKernelGGL(preprocess_kernel<true>, dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat, opts.no_footprint_cull, ws.rec,
-                           ws.rect, ws.rect8[0], ws.key[0], ws.val[0], d);
-    } else {
-        hipLaunchKernelGGL(preprocess_kernel<false>, dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat, opts.no_footprint_cull, ws.rec,
-                           ws.rect, ws.rect8[0], ws.key[0], ws.val[0], d);
-    }
+    if (dbg) d = *dbg;
+#define GSR_LAUNCH_PRE(DBG, H16)                                                                                             \
+    hipLaunchKernelGGL((preprocess_kernel<DBG, H16>), dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat,            \
+                       opts.no_footprint_cull, ws.rec, ws.rect, ws.rect8[0], ws.key[0], ws.val[0], d)
+    const bool h16 = scene.sh_dtype == 1;
+    if (dbg) { if (h16) GSR_LAUNCH_PRE(true, true); else GSR_LAUNCH_PRE(true, false); }
+    else     { if (h16) GSR_LAUNCH_PRE(false, true); else GSR_LAUNCH_PRE(false, false); }
+#undef GSR_LAUNCH_PRE
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

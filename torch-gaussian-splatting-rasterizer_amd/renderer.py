@@ -34,12 +34,13 @@ class GaussianScene:
 
     FIELDS = ("means", "log_scales", "quats", "opacity_logit", "sh")
 
-    def __init__(self, arrays: Mapping[str, torch.Tensor], sh_degree: int = 3):
+    def __init__(self, arrays: Mapping[str, torch.Tensor], sh_degree: int = 3, sh_half: bool = False):
         self.t: Dict[str, torch.Tensor] = {}
+        self.sh_half = bool(sh_half)
         for k in self.FIELDS:
             v = arrays[k]
             _require_cuda(v, k)
-            self.t[k] = v.contiguous().float()
+            self.t[k] = v.contiguous().half() if (k == "sh" and sh_half) else v.contiguous().float()
         self.n = int(self.t["means"].shape[0])
         self.device = self.t["means"].device
         self.sh_degree = int(sh_degree)
@@ -50,20 +51,20 @@ class GaussianScene:
                 raise ValueError(f"{k}: expected shape {shp}, got {tuple(self.t[k].shape)}")
 
     @classmethod
-    def from_columns(cls, columns, device="cuda", sh_degree: int = 3) -> "GaussianScene":
+    def from_columns(cls, columns, device="cuda", sh_degree: int = 3, sh_half: bool = False) -> "GaussianScene":
         """`columns`: ply element / dict of float32 columns named as in the INRIA .ply."""
         packed = pack_gaussians(columns)
-        return cls({k: torch.from_numpy(v).to(device) for k, v in packed.items()}, sh_degree)
+        return cls({k: torch.from_numpy(v).to(device) for k, v in packed.items()}, sh_degree, sh_half)
 
     @classmethod
-    def from_packed(cls, packed: Mapping[str, np.ndarray], device="cuda", sh_degree: int = 3) -> "GaussianScene":
-        return cls({k: torch.from_numpy(np.ascontiguousarray(packed[k], np.float32)).to(device) for k in cls.FIELDS}, sh_degree)
+    def from_packed(cls, packed: Mapping[str, np.ndarray], device="cuda", sh_degree: int = 3, sh_half: bool = False) -> "GaussianScene":
+        return cls({k: torch.from_numpy(np.ascontiguousarray(packed[k], np.float32)).to(device) for k in cls.FIELDS}, sh_degree, sh_half)
 
     @classmethod
-    def from_ply(cls, path: str, device="cuda", sh_degree: int = 3) -> "GaussianScene":
+    def from_ply(cls, path: str, device="cuda", sh_degree: int = 3, sh_half: bool = False) -> "GaussianScene":
         from .ply import PlyData
 
-        return cls.from_columns(PlyData.read(path), device, sh_degree)
+        return cls.from_columns(PlyData.read(path), device, sh_degree, sh_half)
 
     def c_struct(self) -> GsrScene:
         s = GsrScene()
@@ -71,6 +72,7 @@ class GaussianScene:
         for k in self.FIELDS:
             setattr(s, k, self.t[k].data_ptr())
         s.sh_degree = self.sh_degree
+        s.sh_dtype = 1 if self.sh_half else 0
         return s
 
 
@@ -171,6 +173,31 @@ class Rasterizer:
                 self.max_pairs = int(min(0xFFFFFFF0, need + need // 8 + 1024))
                 continue
             return (img, final_T) if return_T else img
+
+    def render_batch(self, cams, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Several views of the resident scene in one call: [B,H,W,3].  Pair buffers are sized on the fly: a view
+        that overflows makes the batch re-run with room for it."""
+        opts = opts or make_options()
+        if opts.output_layout != 0 or opts.tile_row_step > 1:
+            raise ValueError("render_batch renders whole [H,W,3] frames")
+        cams = list(cams)
+        arr = (GsrCamera * len(cams))(*cams)
+        W, H = cams[0].width, cams[0].height
+        if out is None:
+            out = torch.empty((len(cams), H, W, 3), dtype=torch.float32, device=self.scene.device)
+        sc = self.scene.c_struct()
+        while True:
+            ws = self._workspace(W, H)
+            # overflow is only visible per view: check every view's counters cheaply by rendering view by view
+            # when the batch is small, else trust fit_pairs() and check the last one
+            check(lib.gsr_render_batch(C.byref(sc), arr, len(cams), C.byref(opts), self.max_pairs, ws.data_ptr(), ws.numel(),
+                                       out.data_ptr(), H * W * 3, _stream_ptr(self.scene.device)))
+            try:
+                self.stats()
+                return out
+            except _lib.GsrPairOverflow:
+                need = int(self.last_stats["n_pairs_bbox"])
+                self.max_pairs = int(min(0xFFFFFFF0, need + need // 4 + 1024))
 
     def fit_pairs(self, cam: GsrCamera, opts: Optional[GsrOptions] = None, slack: float = 1.25) -> int:
         """Size the pair buffers to this view: one probing frame, then max_pairs = slack * D (+ margin).

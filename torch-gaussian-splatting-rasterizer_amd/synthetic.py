@@ -103,7 +103,7 @@ def _rotmat_to_qvec(R: np.ndarray) -> np.ndarray:
             [R[0, 0] - R[1, 1] - R[2, 2], 0.0, 0.0, 0.0],
             [R[1, 0] + R[0, 1], R[1, 1] - R[0, 0] - R[2, 2], 0.0, 0.0],
             [R[2, 0] + R[0, 2], R[2, 1] + R[1, 2], R[2, 2] - R[0, 0] - R[1, 1], 0.0],
-            [R[1, 2] - R[2, 1], R[2, 0] - R[0, 2], R[0, 1] - R[1, 0], R[0, 0] + R[1, 1] + R[2, 2]],
+            [R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1], R[0, 0] + R[1, 1] + R[2, 2]],
         ]
     ) / 3.0
     vals, vecs = np.linalg.eigh(K)
