@@ -121,11 +121,23 @@ def main():
             return R.enqueue(cam, opts, out=strip_view)
     else:
         opts = renderer.make_options(early_out_T=args.early_out_T, **plan.shard_options(rank))
-        strip_view = fg.own_view()
+        strip_view = fg.own_view(0)
+        state = {"i": 0, "pending": None}
 
         def step():
-            R.enqueue(cam, opts, out=strip_view)
-            return fg.gather()
+            # frame k's strip is gathered asynchronously (RCCL stream) while frame k+1 renders into the other buffer
+            buf = state["i"] & 1
+            state["i"] += 1
+            R.enqueue(cam, opts, out=fg.own_view(buf))
+            h = fg.gather_async(buf)
+            done = fg.finish(state["pending"]) if state["pending"] is not None else None
+            state["pending"] = h
+            return done
+
+        def drain():
+            out = fg.finish(state["pending"]) if state["pending"] is not None else None
+            state["pending"] = None
+            return out
 
     # size the pair buffer to this view once (grows on overflow), outside the timed region
     R.fit_pairs(cam, opts)
@@ -133,12 +145,16 @@ def main():
     shard_stats = dict(R.last_stats)
     for _ in range(args.warmup):
         step()
+    if world > 1:
+        drain()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame = step()
+    if world > 1:
+        frame = drain()  # the last frame's gather completes inside the timed region
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()

@@ -36,11 +36,16 @@ def _worker(rank, world, port, H, W, q):
     assert tuple(own.shape) == plan.strip_shape(rank)
     own.copy_(plan.split(frame, rank)[: own.shape[0]])           # what libgsr would write (output_layout = 2)
     out = fg.gather()
-    ok = True
-    if rank == 0:
-        ok = bool(torch.equal(out, frame))
-    else:
-        ok = out is None
+    ok = bool(torch.equal(out, frame)) if rank == 0 else out is None
+    # double-buffered asynchronous form (what bench.py runs): two frames in flight
+    frame2 = frame.flip(0).contiguous()
+    own1 = fg.own_view(1)
+    own1.copy_(plan.split(frame2, rank)[: own1.shape[0]])
+    h0, h1 = fg.gather_async(0), fg.gather_async(1)
+    a = fg.finish(h0)
+    a = a.clone() if a is not None else None
+    b = fg.finish(h1)
+    ok = ok and (bool(torch.equal(a, frame) and torch.equal(b, frame2)) if rank == 0 else (a is None and b is None))
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, ok))

@@ -266,10 +266,13 @@ def test_tile_row_shards_reassemble_bit_exactly(G, step):
     full = R.render(cam)
     tiles_y = (cam.height + 15) // 16
     out = torch.zeros_like(full)
+    R.render(cam)
+    full_visible = R.last_stats["n_visible"]
     pairs = 0
     for r in range(step):
         strip = R.render(cam, G.renderer.make_options(tile_row_begin=r, tile_row_step=step, output_layout=2))
         pairs += R.last_stats["n_pairs"]
+        assert 0 < R.last_stats["n_visible"] < full_visible       # a shard only preprocesses/sorts what touches its rows
         for k, ty in enumerate(range(r, tiles_y, step)):
             h = min(16, cam.height - ty * 16)
             out[ty * 16: ty * 16 + h] = strip[k * 16: k * 16 + h]

@@ -24,7 +24,7 @@ struct Cam {
 };
 
 template <bool DEBUG, bool SH16>
-__global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, GaussRec *__restrict__ rec,
+__global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, GaussRec *__restrict__ rec,
                                                          ushort4 *__restrict__ rect, uint32_t *__restrict__ rect8, uint32_t *__restrict__ depth_key,
                                                          uint32_t *__restrict__ ident, GsrDebugOut dbg)
 {
@@ -132,6 +132,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
         else {
             tx0 = (int)fx0 >> 4; tx1 = ((int)fx1 >> 4) + 1;
             ty0 = (int)fy0 >> 4; ty1 = ((int)fy1 >> 4) + 1;
+            // multi-GPU shard (tile rows row_begin, row_begin + row_step, ...): a gaussian that touches none of this
+            // rank's rows leaves here, before the 192-B SH read, and never enters this rank's sorts
+            if (row_step > 1) {
+                int r = (ty0 - row_begin) % row_step;
+                if (r < 0) r += row_step;
+                const int first = r == 0 ? ty0 : ty0 + (row_step - r);
+                if (first >= ty1) visible = false;
+            }
         }
     }
 
@@ -180,7 +188,7 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
     if (dbg) d = *dbg;
 #define GSR_LAUNCH_PRE(DBG, H16)                                                                                             \
     hipLaunchKernelGGL((preprocess_kernel<DBG, H16>), dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat,            \
-                       opts.no_footprint_cull, ws.rec, ws.rect, ws.rect8[0], ws.key[0], ws.val[0], d)
+                       opts.no_footprint_cull, opts.tile_row_begin, opts.tile_row_step < 1 ? 1 : opts.tile_row_step, ws.rec, ws.rect, ws.rect8[0], ws.key[0], ws.val[0], d)
     const bool h16 = scene.sh_dtype == 1;
     if (dbg) { if (h16) GSR_LAUNCH_PRE(true, true); else GSR_LAUNCH_PRE(true, false); }
     else     { if (h16) GSR_LAUNCH_PRE(false, true); else GSR_LAUNCH_PRE(false, false); }

@@ -76,25 +76,42 @@ class TileRowPlan:
 
 
 class FrameGather:
-    """Pre-allocated equal-size gather of the strips to rank 0."""
+    """Pre-allocated equal-size gather of the strips to rank 0, double-buffered so that the gather of frame k
+    (RCCL, on the communicator's own stream) can overlap the render of frame k+1."""
 
-    def __init__(self, plan: TileRowPlan, rank: int, device, dtype=torch.float32, group=None):
+    def __init__(self, plan: TileRowPlan, rank: int, device, dtype=torch.float32, group=None, buffers: int = 2):
         self.plan, self.rank, self.group = plan, rank, group
-        self.strip = torch.zeros(plan.padded_shape(), dtype=dtype, device=device)
-        self.recv = ([torch.zeros(plan.padded_shape(), dtype=dtype, device=device) for _ in range(plan.world)]
-                     if rank == 0 and plan.world > 1 else None)
+        self.strips = [torch.zeros(plan.padded_shape(), dtype=dtype, device=device) for _ in range(buffers)]
+        self.recvs = ([[torch.zeros(plan.padded_shape(), dtype=dtype, device=device) for _ in range(plan.world)]
+                       for _ in range(buffers)] if rank == 0 and plan.world > 1 else None)
         self.frame = torch.zeros((plan.height, plan.width, 3), dtype=dtype, device=device) if rank == 0 else None
 
-    def own_view(self) -> torch.Tensor:
-        """The leading rows of the wire buffer that libgsr writes this rank's strip into."""
-        k = len(self.plan.rows[self.rank])
-        return self.strip[: k * TILE]
+    @property
+    def strip(self) -> torch.Tensor:
+        return self.strips[0]
 
-    def gather(self) -> Optional[torch.Tensor]:
-        """Collective: every rank calls it after its strip is complete (stream-ordered). Rank 0 gets the frame."""
+    def own_view(self, buf: int = 0) -> torch.Tensor:
+        """The leading rows of wire buffer `buf` that libgsr writes this rank's strip into."""
+        k = len(self.plan.rows[self.rank])
+        return self.strips[buf][: k * TILE]
+
+    def gather_async(self, buf: int = 0):
+        """Start the collective for wire buffer `buf` (every rank calls it once its strip is enqueued on the
+        current stream).  Returns a handle for finish()."""
         if self.plan.world == 1:
-            return self.plan.assemble([self.strip], self.frame)
-        dist.gather(self.strip, self.recv if self.rank == 0 else None, dst=0, group=self.group)
+            return (buf, None)
+        work = dist.gather(self.strips[buf], self.recvs[buf] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
+        return (buf, work)
+
+    def finish(self, handle) -> Optional[torch.Tensor]:
+        """Wait for a gather (stream-ordered on GPU backends) and, on rank 0, de-interleave into the frame."""
+        buf, work = handle
+        if work is not None:
+            work.wait()
         if self.rank != 0:
             return None
-        return self.plan.assemble(self.recv, self.frame)
+        return self.plan.assemble([self.strips[buf]] if self.plan.world == 1 else self.recvs[buf], self.frame)
+
+    def gather(self, buf: int = 0) -> Optional[torch.Tensor]:
+        """Blocking form: every rank calls it after its strip is complete.  Rank 0 gets the frame."""
+        return self.finish(self.gather_async(buf))
