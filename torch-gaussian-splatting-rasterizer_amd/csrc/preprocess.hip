@@ -110,17 +110,22 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
     // ---- footprint AABB: where can alpha > 1/255 (and power <= 0) hold? -----------------------------
     // alpha > 1/255  <=>  sx dx^2 + sy dy^2 + 2 sxy dx dy < 2 ln(255 op).  For a positive-definite conic that
     // ellipse has the axis-aligned half extents sqrt(2 tau sy / D), sqrt(2 tau sx / D), D = sx sy - sxy^2.
-    // Evaluated in fp64 from the fp32 conic the blend really uses, inflated (1 % on tau, 0.05 px) so that
-    // rounding in the per-pixel fp32 evaluation can never put a contributing pixel outside.
+    // All fp32, made conservative explicitly: D suffers cancellation, its computed value is within 3 ulp of
+    // max(sx sy, sxy^2) of the true one, so D is lowered by 4e-7 * sx * sy (and the test fails over to "no
+    // culling" when that leaves nothing); tau carries a 1 % margin, the extents 1e-5 relative + 0.05 px.  The
+    // per-pixel fp32 evaluation in the blend can therefore never put a contributing pixel outside
+    // (tests/test_gpu_parity.py::test_footprint_culling_is_exact compares against culling disabled, bit for bit).
     float hx = 3.0e38f, hy = 3.0e38f, pthr = -3.0e38f;
     if (visible && !no_cull) {
-        const double D = (double)sx * (double)sy - (double)sxy * (double)sxy;
-        if (sx > 0.0f && sy > 0.0f && D > 0.0) {
-            const double tau = log(255.0 * (double)op);  // > 0 because op > 1/255
-            const double tau2 = 2.0 * 1.01 * tau;
-            hx = (float)(sqrt(tau2 * (double)sy / D) * 1.0001 + 0.05);
-            hy = (float)(sqrt(tau2 * (double)sx / D) * 1.0001 + 0.05);
-            pthr = (float)(-1.01 * tau * 1.4426950408889634 - 1.0e-3);  // -log2(255 op), loosened (footprint.h)
+        const float sxsy = sx * sy;
+        const float D = (sxsy - sxy * sxy) - 4.0e-7f * sxsy;
+        if (sx > 0.0f && sy > 0.0f && D > 0.0f && D > 1.0e-6f * sxsy) {  // also keep the conic's condition number sane
+            const float tau = logf(255.0f * op);  // > 0 because op > 1/255
+            const float tau2 = 2.02f * tau + 1.0e-5f;
+            const float invD = 1.0f / D;
+            hx = sqrtf(tau2 * sy * invD) * 1.00001f + 0.05f;
+            hy = sqrtf(tau2 * sx * invD) * 1.00001f + 0.05f;
+            pthr = -1.01f * 1.4426950408889634f * tau - 1.0e-3f;  // -log2(255 op), loosened (footprint.h)
         }
     }
     // refine the reference rect [x_min,x_max) x [y_min,y_max) by the footprint; pixel centres are integers (Q9)
