@@ -208,7 +208,7 @@ def main():
         st = R.stats()
         stage = [float(np.mean([e[k].elapsed_time(e[k + 1]) for e in ev])) for k in range(3)]
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
-        E, P, V = st["n_pairs"], W * H, st["n_visible"]
+        E, P, V = st["fetched_entries"], W * H, st["n_visible"]  # E = entries actually fetched
         blend_bytes = 40.0 * E + 12.0 * P + 8.0 * tiles
         pre_bytes = (140.0 if sh_half else 236.0) * n + 64.0 * V
         achieved = blend_bytes / (stage[2] * 1e-3) / 1e9
@@ -222,12 +222,14 @@ def main():
         result["roofline"] = {"kernel": "gsr::blend_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                               "algorithmic_bytes_per_launch": blend_bytes, "avg_kernel_ms": stage[2],
-                              "note": "blend is VALU/exp-bound in exact mode (SURVEY.md §7 hard part 1); see valu_frac"}
-        # honesty figure: pixel evaluations actually issued = 64 per evaluated (quadrant, entry);
-        # ~22 fp32 VALU ops each (2 sub, 5 quadratic, exp2 (counted 4), mul, min, 2 cmp, select, 6 blend)
+                              "note": "blend is VALU-bound in exact mode (SURVEY.md §7 hard part 1): see valu_issue_frac; traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE from profiles/"}
+        # honesty figure: the blend is VALU-bound.  64 pixel evaluations per evaluated (quadrant, entry);
+        # rocprofv3 PMC (profiles/r1_pmc.json) counts 21.4 VALU wave-instructions per of them (17 in the inner loop + culling,
+        # staging).  Peak issue = one fp32 VALU wave-instruction per 2 cycles per SIMD (tools/valu_microbench.hip), 1024 SIMDs,
+        # 2.4 GHz; v_exp_f32 costs 4 and v_cmp/v_cndmask ~1.5 of those slots, so the pipe is fuller than this fraction says.
         evals = 64.0 * st["wave_entries"]
         result["roofline"]["pixel_evaluations"] = evals
-        result["roofline"]["valu_frac_of_fp32_peak"] = evals * 22.0 / (stage[2] * 1e-3) / (FP32_PEAK_TFLOPS * 1e12 / 2.0)
+        result["roofline"]["valu_issue_frac"] = st["wave_entries"] * 21.4 / (stage[2] * 1e-3) / (1024 * 1.2e9)
         result["stage_ms"] = {"preprocess": stage[0], "bin_sort": stage[1], "blend": stage[2]}
         result["stage_hbm_gbs"] = {"preprocess": pre_bytes / (stage[0] * 1e-3) / 1e9}
         result["stats"] = st
@@ -259,7 +261,7 @@ def main():
 
             cores = host_threads()
             torch.set_num_threads(cores)  # the reference sets cpu_count()-1 (rasterize.py:323)
-            s = torch_loop.timed_sample(pre, order, W, H, budget_s=args.cpu_budget_s)
+            s = torch_loop.timed_sample(pre, order, W, H, budget_s=args.cpu_budget_s, max_gaussians=400_000)
             result["cpu_baseline"] = {
                 "value": 1.0 / s["extrapolated_frame_s"], "unit": "frames/s", "cores": cores, "kind": "port",
                 "sample": (f"reference per-gaussian torch loop (oracle/torch_loop.py): uniform random sample of {s['sampled']} of the "

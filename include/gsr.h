@@ -95,6 +95,7 @@ typedef struct GsrStats {
     uint32_t max_list_len;  /* longest per-tile list */
     uint32_t _pad;
     uint64_t wave_entries;  /* (8x8 quadrant, entry) pairs the blend actually evaluated: 64 pixel evaluations each */
+    uint64_t fetched_entries; /* list entries the blend staged (<= n_pairs: a saturated tile stops fetching) */
 } GsrStats;
 
 /* Optional intermediates of gsr_preprocess, one entry per gaussian, any pointer may be NULL.

@@ -178,7 +178,7 @@ def test_medium_scene_vs_oracle(G):
     oimg, drawn = G.orc.render(G.utils.pack_gaussians(cols), ocam)
     st = R.last_stats
     assert 0 < st["n_visible"] <= drawn and st["n_visible"] < st["n_pairs"] <= st["n_pairs_bbox"] and st["overflow"] == 0
-    assert 0 < st["wave_entries"] <= 4 * st["n_pairs"]
+    assert 0 < st["wave_entries"] <= 4 * st["fetched_entries"] and 0 < st["fetched_entries"] <= st["n_pairs"]
     assert_frames_close(img, oimg)
 
 

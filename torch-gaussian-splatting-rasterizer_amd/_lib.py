@@ -83,6 +83,7 @@ class GsrStats(C.Structure):
         ("max_list_len", C.c_uint32),
         ("_pad", C.c_uint32),
         ("wave_entries", C.c_uint64),
+        ("fetched_entries", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -303,7 +303,7 @@ int gsr_render_batch(const GsrScene *scene, const GsrCamera *cams, int32_t n_cam
 int gsr_read_stats(const void *workspace, size_t workspace_bytes, GsrStats *out, void *stream)
 {
     if (!workspace || !out || workspace_bytes < sizeof(FrameCtrl)) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
-    static_assert(sizeof(GsrStats) == 32, "GsrStats is the head of FrameCtrl");
+    static_assert(sizeof(GsrStats) == 40, "GsrStats is the head of FrameCtrl");
     hipStream_t s = static_cast<hipStream_t>(stream);
     GSR_HIP(hipMemcpyAsync(out, workspace, sizeof(GsrStats), hipMemcpyDeviceToHost, s));
     GSR_HIP(hipStreamSynchronize(s));

@@ -132,12 +132,14 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
     float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
     bool wave_done = false;
     uint32_t evaluated = 0;  // wave-uniform
+    uint32_t fetched = 0;    // workgroup-uniform
     if (tid == 0) s_done = 0;
 
     for (uint32_t batch = range.x; batch < range.y; batch += 256) {
         __syncthreads();  // previous batch fully consumed (and s_done initialised)
         if (s_done == 4) break;  // uniform: every wave saturated
         const uint32_t i = batch + tid;
+        fetched += min(256u, range.y - batch);
         if (i < range.y) {
             const GaussRec *r = a.rec + a.pval[i];
             s0[tid] = r->q0;
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
     }
 
     if (lane == 0 && evaluated) atomicAdd(&a.ctrl->wave_entries, (unsigned long long)evaluated);
+    if (tid == 0 && fetched) atomicAdd(&a.ctrl->fetched_entries, (unsigned long long)fetched);
     if (px < a.W && py < a.H) {
         const bool drawn = px < a.xlim && py < a.ylim;  // Q1: last column / row stay black, T stays 1
         const float r = drawn ? Cr : 0.0f, g = drawn ? Cg : 0.0f, b = drawn ? Cb : 0.0f;

@@ -10,7 +10,7 @@ namespace gsr {
 
 // ---------------------------------------------------------------------------------------------
 // Device control block at the head of the workspace.  Zeroed at the start of every frame.
-// The first 8 words are GsrStats verbatim.
+// The first 40 bytes are GsrStats verbatim.
 // ---------------------------------------------------------------------------------------------
 struct FrameCtrl {
     uint32_t n_visible;     // V  (written by the first depth-sort scatter pass)
@@ -20,6 +20,7 @@ struct FrameCtrl {
     uint32_t max_list_len;
     uint32_t n_slots;       // min(D, max_pairs): pair slots written by the emit kernel
     unsigned long long wave_entries;  // (quadrant, entry) pairs evaluated by the blend
+    unsigned long long fetched_entries;  // list entries staged by the blend
     uint32_t digit_tot[256]; // per-digit totals of the radix pass in flight
     uint32_t batch_overflow; // sticky across the views of gsr_render_batch (not cleared per frame)
     uint32_t batch_need;     // largest D seen in the batch
