@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--workload", default="garden", choices=sorted(WORKLOADS))
     ap.add_argument("--n", type=int, default=0, help="override the gaussian count (0 = the workload's)")
     ap.add_argument("--early-out-T", type=float, default=0.0)
+    ap.add_argument("--blend-impl", type=int, default=0, help="0/1 vector-ALU blend (reference-grade), 2 matrix-pipe blend")
     ap.add_argument("--sh-half", action="store_true", help="store SH coefficients as fp16 (implied by --workload bicycle)")
     ap.add_argument("--camera", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -114,13 +115,13 @@ def main():
     fg = gdist.FrameGather(plan, rank, dev)
     R = renderer.Rasterizer(scene)
     if world == 1:  # no sharding: blend straight into the frame
-        opts = renderer.make_options(early_out_T=args.early_out_T)
+        opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl)
         strip_view = fg.frame
 
         def step():
             return R.enqueue(cam, opts, out=strip_view)
     else:
-        opts = renderer.make_options(early_out_T=args.early_out_T, **plan.shard_options(rank))
+        opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl, **plan.shard_options(rank))
         strip_view = fg.own_view(0)
         state = {"i": 0, "pending": None}
 
@@ -176,7 +177,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "gaussians": n, "width": W, "height": H, "camera": args.camera,
                        "sharding": f"tile rows interleaved over {world} GPU(s), RCCL gather to rank 0" if world > 1 else "none",
-                       "reference_compat": True, "early_out_T": args.early_out_T, "sh_storage": "f16" if sh_half else "f32"},
+                       "reference_compat": True, "early_out_T": args.early_out_T, "sh_storage": "f16" if sh_half else "f32",
+                       "blend_impl": "mfma" if args.blend_impl == 2 else "valu"},
             "stats_rank0_shard": shard_stats,
         }
 
@@ -188,7 +190,7 @@ def main():
 
         ws = R._workspace(W, H)
         sc = scene.c_struct()
-        full_opts = renderer.make_options(early_out_T=args.early_out_T)
+        full_opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl)
         out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
         stream = torch.cuda.current_stream(dev)
         sp = int(stream.cuda_stream)

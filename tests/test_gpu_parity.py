@@ -152,6 +152,28 @@ def test_multi_camera_batch(G):
     assert not torch.equal(singles[0], singles[1])
 
 
+def test_matrix_pipe_blend_matches_vector_blend(G):
+    """blend_impl = 2 evaluates the quadratic on the MFMA pipe (expanded polynomial: ~1e-5 absolute in the exponent).
+    Same lists, same counters; frames within the oracle tolerance of each other and of the oracle."""
+    cols, cam, ocam = _medium(G)
+    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
+    a, Ta = R.render(cam, return_T=True)
+    sa = dict(R.last_stats)
+    b, Tb = R.render(cam, G.renderer.make_options(blend_impl=2), return_T=True)
+    sb = dict(R.last_stats)
+    for k in ("n_visible", "n_pairs", "n_pairs_bbox"):
+        assert sa[k] == sb[k]
+    oimg, _ = G.orc.render(G.utils.pack_gaussians(cols), ocam)
+    assert_frames_close(b.cpu().numpy(), oimg, min_db=95.0)
+    assert psnr(b.cpu().numpy(), a.cpu().numpy()) >= 95.0
+    assert (Ta - Tb).abs().max() < 1e-3
+    g = load_golden("f2_small.npz")
+    cam2, _ = _cams(G, g)
+    img = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(golden_columns(g))).render(
+        cam2, G.renderer.make_options(blend_impl=2)).cpu().numpy()
+    assert psnr(img, g["image"]) >= 95.0 and not img[-1].any() and not img[:, -1].any()
+
+
 def test_reference_screen_layout(G):
     g = load_golden("f2_small.npz")
     cam, _ = _cams(G, g)

@@ -70,7 +70,8 @@ class GsrOptions(C.Structure):
         ("tile_row_step", C.c_int32),
         ("output_layout", C.c_int32),
         ("no_footprint_cull", C.c_int32),
-        ("_pad", C.c_int32 * 2),
+        ("blend_impl", C.c_int32),
+        ("_pad", C.c_int32),
     ]
 
 

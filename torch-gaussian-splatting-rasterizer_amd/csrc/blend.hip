@@ -28,25 +28,11 @@
 // + 8 per tile range.  At ~20 VALU issues per (pixel, entry) evaluation the kernel is VALU/exp bound,
 // not HBM bound; both fractions are reported by bench.py.
 #include "gsr_internal.h"
+#include "blend_args.h"
 #include "footprint.h"
 
 namespace gsr {
 
-struct BlendArgs {
-    const uint2 *ranges;
-    const uint32_t *pval;
-    const GaussRec *rec;
-    float *out;
-    float *out_T;
-    FrameCtrl *ctrl;
-    const int *order;     // tile launch order (tile_order_kernel), -1 = empty slot
-    int W, H;
-    int xlim, ylim;       // pixels x < xlim, y < ylim are drawn (W-1/H-1 in reference_compat: Q1)
-    int tiles_x;
-    int row_begin, row_step, rows;  // tile rows of this shard: row_begin + k*row_step, k in [0, rows)
-    int layout;
-    float early_T;
-};
 
 // one (pixel, entry) evaluation; g = {mean_x, mean_y}, c = {A, B, C, -}, o = {log2(opacity), r, g, b}.
 // ~16 VALU issues: the kernel is VALU-bound (tools/valu_microbench.hip prices them), so every one counts:
@@ -226,6 +212,7 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     a.order = ws.tile_order;
     hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(256), 0, s, ws.ranges, ws.ctrl, a.tiles_x, a.row_begin, a.row_step, a.rows,
                        slots_per_group, ws.tile_order);
+    if (opts.blend_impl == 2) return launch_blend_mfma(a, 8u * (unsigned)slots_per_group, s);
     hipLaunchKernelGGL(blend_kernel, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
