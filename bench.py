@@ -59,31 +59,59 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="garden", choices=sorted(WORKLOADS))
-    ap.add_argument("--n", type=int, default=0, help="override the gaussian count (0 = the workload's)")
+    ap.add_argument("--gaussians", type=int, default=0, help="override the gaussian count (0 = the workload's)")
     ap.add_argument("--early-out-T", type=float, default=0.0)
     ap.add_argument("--blend-impl", type=int, default=0, help="0/1 vector-ALU blend (reference-grade), 2 matrix-pipe blend")
     ap.add_argument("--sh-half", action="store_true", help="store SH coefficients as fp16 (implied by --workload bicycle)")
     ap.add_argument("--camera", type=int, default=0)
+    ap.add_argument("--camera-set", default="single", choices=["single", "all"],
+                    help="single: every step renders --camera; all: steps cycle over the whole camera set (configs[3])")
+    ap.add_argument("--input_dir", default="", help="real data: MipNeRF-360 scene dir with sparse/0/{images,cameras}.bin")
+    ap.add_argument("--trained_model_path", default="", help="real data: INRIA model dir (point_cloud/iteration_30000/point_cloud.ply)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     return ap.parse_args()
 
 
+def build_real_workload(args):
+    """SURVEY.md §8(d) real-data mode: the trained ply + COLMAP poses; the frame is forced to 1920x1080 with a
+    consistent pinhole (focal = fx_full * 1920 / cam.width); test cameras = every 8th image by sorted name."""
+    from gsr_amd import ply, utils
+
+    W, H = 1920, 1080
+    images, cams = utils.read_scene(args.input_dir)
+    cam0 = cams[1]
+    f = float(cam0.params[0]) * W / float(cam0.width)
+    ordered = sorted(images.values(), key=lambda im: im.name)
+    test = ordered[::8]
+    poses = test if args.camera_set == "all" else [ordered[args.camera % len(ordered)]]
+    # cam_args in gsr_camera_setup's convention: full-res focal 2f over a 2W x 2H sensor -> fov and f/1 at W x H
+    cam_list = [(im.qvec, im.tvec, 2 * f, 2 * f, 2 * W, 2 * H, W, H) for im in poses]
+    cols = ply.read_gaussians_columns(os.path.join(args.trained_model_path, "point_cloud/iteration_30000/point_cloud.ply"))
+    n = len(cols["x"])
+    return cols, cam_list, n, W, H, f"real data: {args.input_dir} + {args.trained_model_path}, {len(cam_list)} camera(s)"
+
+
 def build_workload(args):
     from gsr_amd import synthetic
 
+    if args.input_dir and args.trained_model_path:
+        return build_real_workload(args)
     gen, n, seed, W, H, desc = WORKLOADS[args.workload]
-    if args.n:
-        n = args.n
+    if args.gaussians:
+        n = args.gaussians
     cols = getattr(synthetic, gen)(n, seed)
     if gen == "uniform_box":
-        pose = synthetic.box_camera()
+        poses = [synthetic.box_camera()]
+    elif args.camera_set == "all":
+        poses = synthetic.ring_cameras(25)
     else:
-        pose = synthetic.ring_cameras(25)[args.camera]
+        poses = [synthetic.ring_cameras(25)[args.camera]]
     fx = synthetic.pinhole_focal(W)
-    cam_args = (pose.qvec, pose.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H)  # on-disk convention: full-res = 2x, scale-factor 2
-    return cols, cam_args, n, W, H, desc
+    # on-disk convention: full-res = 2x, scale-factor 2
+    cam_list = [(p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H) for p in poses]
+    return cols, cam_list, n, W, H, desc
 
 
 def main():
@@ -95,31 +123,45 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GSR_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
+    # strips are staged through the host); the measured configuration is nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from gsr_amd import dist as gdist
     from gsr_amd import renderer, utils
 
-    cols, cam_args, n, W, H, desc = build_workload(args)
+    cols, cam_list, n, W, H, desc = build_workload(args)
+    cam_args = cam_list[0]
     packed = utils.pack_gaussians(cols)
     del cols
     sh_half = args.sh_half or args.workload == "bicycle"
     scene = renderer.GaussianScene.from_packed(packed, device=dev, sh_half=sh_half)
-    cam = renderer.make_camera(*cam_args)
+    cams = [renderer.make_camera(*c) for c in cam_list]
+    cam = cams[0]
+    ncam = len(cams)
     plan = gdist.TileRowPlan(H, W, world)
     fg = gdist.FrameGather(plan, rank, dev)
     R = renderer.Rasterizer(scene)
+    state1 = {"i": 0}
     if world == 1:  # no sharding: blend straight into the frame
         opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl)
         strip_view = fg.frame
 
         def step():
-            return R.enqueue(cam, opts, out=strip_view)
+            c = cams[state1["i"] % ncam]
+            state1["i"] += 1
+            return R.enqueue(c, opts, out=strip_view)
     else:
         opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl, **plan.shard_options(rank))
         strip_view = fg.own_view(0)
@@ -128,8 +170,9 @@ def main():
         def step():
             # frame k's strip is gathered asynchronously (RCCL stream) while frame k+1 renders into the other buffer
             buf = state["i"] & 1
+            c = cams[state["i"] % ncam]
             state["i"] += 1
-            R.enqueue(cam, opts, out=fg.own_view(buf))
+            R.enqueue(c, opts, out=fg.own_view(buf))
             h = fg.gather_async(buf)
             done = fg.finish(state["pending"]) if state["pending"] is not None else None
             state["pending"] = h
@@ -140,14 +183,17 @@ def main():
             state["pending"] = None
             return out
 
-    # size the pair buffer to this view once (grows on overflow), outside the timed region
-    R.fit_pairs(cam, opts)
+    # size the pair buffer to the heaviest view once (grows on overflow), outside the timed region
+    need = max(R.fit_pairs(c, opts) for c in cams)
+    R.max_pairs = need
     R.render(cam, opts, out=strip_view)
     shard_stats = dict(R.last_stats)
     for _ in range(args.warmup):
         step()
+    state1["i"] = 0
     if world > 1:
         drain()
+        state["i"] = 0
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -175,7 +221,8 @@ def main():
             "value": args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "gaussians": n, "width": W, "height": H, "camera": args.camera,
+            "config": {"workload": f"{args.workload}: {desc}", "gaussians": n, "width": W, "height": H,
+                       "camera": args.camera if ncam == 1 else f"cycling over {ncam} cameras",
                        "sharding": f"tile rows interleaved over {world} GPU(s), RCCL gather to rank 0" if world > 1 else "none",
                        "reference_compat": True, "early_out_T": args.early_out_T, "sh_storage": "f16" if sh_half else "f32",
                        "blend_impl": "mfma" if args.blend_impl == 2 else "valu"},
@@ -185,6 +232,8 @@ def main():
     # ---- single-GPU extras: per-stage timing, roofline, PSNR vs the oracle, CPU baseline -------------------
     if rank == 0 and world == 1:
         import ctypes as C
+
+        frame = R.enqueue(cam, opts, out=strip_view)  # the frame checked against the oracle below is camera 0's
 
         from gsr_amd._lib import check, lib
 

@@ -71,3 +71,17 @@ def test_gpu_entry_points_reject_bad_arguments_without_touching_a_gpu():
     assert _lib.lib.gsr_render_forward(C.byref(sc), C.byref(cam), C.byref(o), 100, None, 0, None, None, None) == _lib.GSR_ERR_BAD_ARG
     assert b"null" in _lib.lib.gsr_last_error()
     assert _lib.lib.gsr_blend(0, C.byref(cam), C.byref(o), 0, None, 0, None, None, None) == _lib.GSR_ERR_BAD_ARG
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under the package directory (nor bench.py outside its checker legs)
+    may import it, and the package has no CPU fallback for the HIP path."""
+    pkg = os.path.join(REPO, "torch-gaussian-splatting-rasterizer_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(root, f)).read()
+                assert "cpu_oracle" not in text and "gsr_oracle" not in text and "torch_loop" not in text, f
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+    lib_src = open(os.path.join(pkg, "_lib.py")).read()
+    assert "There is no CPU fallback" in lib_src and "raise ImportError" in lib_src

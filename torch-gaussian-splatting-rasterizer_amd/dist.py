@@ -95,21 +95,34 @@ class FrameGather:
         k = len(self.plan.rows[self.rank])
         return self.strips[buf][: k * TILE]
 
+    def _host_staged(self) -> bool:
+        """gloo cannot move device memory: GPU strips go through host buffers (rehearsal of the multi-rank path on a
+        box without RCCL peers; the production backend is nccl = RCCL, device to device)."""
+        return self.strips[0].is_cuda and dist.get_backend(self.group) == "gloo"
+
     def gather_async(self, buf: int = 0):
         """Start the collective for wire buffer `buf` (every rank calls it once its strip is enqueued on the
         current stream).  Returns a handle for finish()."""
         if self.plan.world == 1:
-            return (buf, None)
+            return (buf, None, None)
+        if self._host_staged():
+            send = self.strips[buf].cpu()  # synchronises with the render of this strip
+            recv = [torch.empty_like(send) for _ in range(self.plan.world)] if self.rank == 0 else None
+            work = dist.gather(send, recv, dst=0, group=self.group, async_op=True)
+            return (buf, work, recv)
         work = dist.gather(self.strips[buf], self.recvs[buf] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
-        return (buf, work)
+        return (buf, work, None)
 
     def finish(self, handle) -> Optional[torch.Tensor]:
         """Wait for a gather (stream-ordered on GPU backends) and, on rank 0, de-interleave into the frame."""
-        buf, work = handle
+        buf, work, host = handle
         if work is not None:
             work.wait()
         if self.rank != 0:
             return None
+        if host is not None:
+            for dst, src in zip(self.recvs[buf], host):
+                dst.copy_(src)
         return self.plan.assemble([self.strips[buf]] if self.plan.world == 1 else self.recvs[buf], self.frame)
 
     def gather(self, buf: int = 0) -> Optional[torch.Tensor]:
