@@ -87,7 +87,9 @@ typedef struct GsrOptions {
                                  2: quadratic evaluated on the matrix pipe (v_mfma_f32_32x32x2_f32) as [gaussian coefficients]
                                  x [pixel basis]: same frame within ~1e-5 absolute in the exponent (measured 125 dB vs the oracle); an
                                  experiment: 33 % fewer VALU instructions but currently ~6 % slower (see blend_mfma.hip). */
-    int32_t _pad;
+    int32_t draw_limit;       /* 0 (default): blend everything.  k > 0: blend only the first k gaussians of the reference's
+                                 draw order (depth order restricted to those its skip guard rasterize.py:441 lets through) —
+                                 the progressive frames of --generate_video (rasterize.py:448-450). */
 } GsrOptions;
 
 /* Counters of one frame (device -> host with gsr_read_stats). */

@@ -131,6 +131,30 @@ def test_run_rasterization_cli_reproduces_the_reference_frame(mods, tmp_path):
         mods.rasterize.render_scene(scene_dir, model_dir, 0, 2)
 
 
+def test_generate_video_writes_the_reference_frame_sequence(mods, tmp_path):
+    from click.testing import CliRunner
+    from PIL import Image
+
+    g = load_golden("f2_small.npz")
+    scene_dir, model_dir = _write_scene(mods, str(tmp_path), g)
+    out_dir = str(tmp_path / "video")
+    res = CliRunner().invoke(mods.rasterize.run_rasterization, [
+        "--input_dir", scene_dir, "--trained_model_path", model_dir, "--output_path", out_dir,
+        "--scene-index", str(int(g["image_id"])), "--scale-factor", "2", "--generate_video"], catch_exceptions=False)
+    assert res.exit_code == 0, res.output
+    n_drawn = len(g["draw_order"])
+    names = sorted(os.listdir(os.path.join(out_dir, "images")))
+    steps = list(range(0, n_drawn, 1000))
+    assert names[: len(steps)] == [f"image_iter_{str(s).zfill(7)}.png" for s in steps] and len(names) == len(steps) + 40
+    # frame 0 holds exactly the first drawn gaussian; the padding frames repeat the last saved frame
+    first = np.asarray(Image.open(os.path.join(out_dir, "images", names[0])))
+    assert first.shape == (int(g["height"]), int(g["width"]), 3) and first.any()
+    last_saved = np.asarray(Image.open(os.path.join(out_dir, "images", names[len(steps) - 1])))
+    assert np.array_equal(np.asarray(Image.open(os.path.join(out_dir, "images", names[-1]))), last_saved)
+    final = np.load(os.path.join(out_dir, "render.npy"))
+    assert psnr(final, g["image"]) >= 100.0
+
+
 def test_cpu_tensors_are_refused(mods):
     with pytest.raises(RuntimeError, match="no CPU path"):
         mods.rasterize.project_to_camera_space(torch.zeros(4, 3), torch.eye(4))

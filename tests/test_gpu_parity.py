@@ -174,6 +174,28 @@ def test_matrix_pipe_blend_matches_vector_blend(G):
     assert psnr(img, g["image"]) >= 95.0 and not img[-1].any() and not img[:, -1].any()
 
 
+@pytest.mark.parametrize("name,prefix", [("f2_small.npz", ""), ("f3_edge.npz", "a_")])
+def test_progressive_render_matches_reference_draw_order(G, name, prefix):
+    """draw_limit = k blends exactly the first k gaussians of the reference's draw order (rasterize.py:440-450):
+    checked against the oracle's loop stopped after k drawn gaussians, k spanning the whole order."""
+    g = load_golden(name)
+    cols = golden_columns(g)
+    cam, ocam = _cams(G, g, prefix)
+    packed = G.utils.pack_gaussians(cols)
+    pre = G.orc.preprocess(packed, ocam)
+    order = G.orc.depth_order(pre["cam_means"])
+    n_drawn = len(g[prefix + "draw_order"])
+    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
+    full = R.render(cam)
+    for k in (1, 2, 7, n_drawn // 3, n_drawn - 1, n_drawn, n_drawn + 50):
+        img = R.render(cam, G.renderer.make_options(draw_limit=k)).cpu().numpy()
+        screen, _, drawn = G.orc.composite(order, pre, cam.width, cam.height, limit=k)
+        assert drawn == min(k, n_drawn)
+        assert_frames_close(img, screen.transpose(1, 0, 2))
+        assert R.last_stats["n_visible"] == n_drawn                # the sort keeps every gaussian the reference draws
+    assert torch.equal(R.render(cam, G.renderer.make_options(draw_limit=n_drawn)), full)
+
+
 def test_reference_screen_layout(G):
     g = load_golden("f2_small.npz")
     cam, _ = _cams(G, g)

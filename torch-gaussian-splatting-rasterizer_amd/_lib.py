@@ -71,7 +71,7 @@ class GsrOptions(C.Structure):
         ("output_layout", C.c_int32),
         ("no_footprint_cull", C.c_int32),
         ("blend_impl", C.c_int32),
-        ("_pad", C.c_int32),
+        ("draw_limit", C.c_int32),
     ]
 
 

@@ -68,14 +68,14 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t
                                                                   const uint32_t *__restrict__ sorted_rect8, const FrameCtrl *ctrl,
                                                                   const ushort4 *__restrict__ rect, Shard sh,
                                                                   uint32_t *__restrict__ blk_sum, uint2 *__restrict__ ranges,
-                                                                  int n_tiles)
+                                                                  int n_tiles, uint32_t draw_limit)
 {
     __shared__ uint32_t scratch[8];
     const uint32_t n = ctrl->n_visible;
     const uint32_t r = blockIdx.x * EMIT_THREADS + threadIdx.x;
     if (r < (uint32_t)n_tiles) ranges[r] = make_uint2(0u, 0u);  // tile ranges are rebuilt every frame
     uint32_t cnt = 0;
-    if (r < n) {
+    if (r < n && r < draw_limit) {  // r = rank in the draw order
         int first;
         cnt = tiles_of(rect_of<PACKED>(r, sorted_ids, sorted_rect8, rect), sh, &first);
     }
@@ -139,7 +139,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
                                                                  const ushort4 *__restrict__ rect, Shard sh, int tiles_x,
                                                                  const GaussRec *__restrict__ rec,
                                                                  const uint32_t *__restrict__ blk_off, uint32_t max_pairs,
-                                                                 uint32_t *__restrict__ pkey, uint32_t *__restrict__ pval)
+                                                                 uint32_t *__restrict__ pkey, uint32_t *__restrict__ pval,
+                                                                 uint32_t draw_limit)
 {
     __shared__ uint32_t scratch[8];
     __shared__ uint32_t s_off[EMIT_THREADS];   // exclusive pair offset of each gaussian inside the workgroup
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
     uint32_t cnt = 0, g = 0;
     int first = 0;
     ushort4 rc = make_ushort4(0, 0, 0, 0);
-    if (r < n) {
+    if (r < n && r < draw_limit) {
         g = sorted_ids[r];
         rc = rect_of<PACKED>(r, sorted_ids, sorted_rect8, rect);
         cnt = tiles_of(rc, sh, &first);
@@ -229,20 +230,21 @@ int launch_binning(const GsrCamera &cam, const GsrOptions &opts, const Workspace
     const uint32_t *ids = ws.val[sorted_buf];
     const uint32_t *r8 = ws.rect8[sorted_buf];
     const uint32_t cap = (uint32_t)ws.max_pairs;
+    const uint32_t limit = opts.draw_limit > 0 ? (uint32_t)opts.draw_limit : 0xFFFFFFFFu;
     if (packed_rect) {
         hipLaunchKernelGGL(pair_count_kernel<true>, dim3(nblk), dim3(EMIT_THREADS), 0, s, ids, r8, ws.ctrl, ws.rect, sh, ws.blk_sum,
-                           ws.ranges, n_tiles);
+                           ws.ranges, n_tiles, limit);
     } else {
         hipLaunchKernelGGL(pair_count_kernel<false>, dim3(nblk), dim3(EMIT_THREADS), 0, s, ids, r8, ws.ctrl, ws.rect, sh, ws.blk_sum,
-                           ws.ranges, n_tiles);
+                           ws.ranges, n_tiles, limit);
     }
     hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, ws.blk_sum, nblk_n, ws.ctrl, cap);
     if (packed_rect) {
         hipLaunchKernelGGL(pair_emit_kernel<true>, dim3(nblk_n), dim3(EMIT_THREADS), 0, s, ids, r8, ws.ctrl, ws.rect, sh, ws.tiles_x,
-                           ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0]);
+                           ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0], limit);
     } else {
         hipLaunchKernelGGL(pair_emit_kernel<false>, dim3(nblk_n), dim3(EMIT_THREADS), 0, s, ids, r8, ws.ctrl, ws.rect, sh, ws.tiles_x,
-                           ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0]);
+                           ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0], limit);
     }
     GSR_HIP(hipGetLastError());
     return GSR_OK;

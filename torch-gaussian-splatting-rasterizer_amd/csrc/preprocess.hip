@@ -24,7 +24,7 @@ struct Cam {
 };
 
 template <bool DEBUG, bool SH16>
-__global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, GaussRec *__restrict__ rec,
+__global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, GaussRec *__restrict__ rec,
                                                          ushort4 *__restrict__ rect, uint32_t *__restrict__ rect8, uint32_t *__restrict__ depth_key,
                                                          uint32_t *__restrict__ ident, GsrDebugOut dbg)
 {
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
     visible = visible && (compat ? (sx != 0.0f && sy != 0.0f && sxy != 0.0f) : (det != 0.0f));
     // finite inputs only (the reference would write garbage rects for NaN/Inf; we drop them)
     visible = visible && (fabsf(mx) < 1e9f) && (fabsf(my) < 1e9f) && (spread < 1e9f) && (sx == sx) && (sy == sy) && (sxy == sxy);
+    const bool ref_drawn = visible;  // exactly the gaussians the reference's loop rasterizes (its iteration_step counts these)
     // Exact extra cull: alpha = opacity * exp(power), power <= 0, can never exceed 1/255 if opacity <= 1/255 (:285-291)
     visible = visible && (op > GSR_MIN_ALPHA);
 
@@ -157,7 +158,18 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
         if (DEBUG && dbg.rgb) { dbg.rgb[3 * i] = rgb[0]; dbg.rgb[3 * i + 1] = rgb[1]; dbg.rgb[3 * i + 2] = rgb[2]; }
     }
 
-    if (!visible) { depth_key[i] = KEY_INVALID; return; }
+    if (!visible) {
+        // progressive render (draw_limit): the depth rank must count every gaussian the reference draws, also those
+        // that cannot touch a pixel here; they stay in the sort with an empty tile rect
+        if (keep_ref_drawn && ref_drawn) {
+            depth_key[i] = __float_as_uint(cm[2]);
+            rect[i] = make_ushort4(0, 0, 0, 0);
+            rect8[i] = 1u;  // packed {x0 = 1, y0 = 0, x1 - 1 = 0, y1 - 1 = 0}: zero width, i.e. no tiles
+        } else {
+            depth_key[i] = KEY_INVALID;
+        }
+        return;
+    }
     depth_key[i] = __float_as_uint(cm[2]);  // z >= 0.2 > 0: IEEE bits are monotone in z (rasterize.py:424-425)
     rect[i] = make_ushort4((unsigned short)tx0, (unsigned short)ty0, (unsigned short)tx1, (unsigned short)ty1);
     rect8[i] = (uint32_t)(tx0 & 255) | ((uint32_t)(ty0 & 255) << 8) | ((uint32_t)((tx1 - 1) & 255) << 16) | ((uint32_t)((ty1 - 1) & 255) << 24);
@@ -193,7 +205,7 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
     if (dbg) d = *dbg;
 #define GSR_LAUNCH_PRE(DBG, H16)                                                                                             \
     hipLaunchKernelGGL((preprocess_kernel<DBG, H16>), dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat,            \
-                       opts.no_footprint_cull, opts.tile_row_begin, opts.tile_row_step < 1 ? 1 : opts.tile_row_step, ws.rec, ws.rect, ws.rect8[0], ws.key[0], ws.val[0], d)
+                       opts.no_footprint_cull, opts.tile_row_begin, opts.tile_row_step < 1 ? 1 : opts.tile_row_step, opts.draw_limit > 0 ? 1 : 0, ws.rec, ws.rect, ws.rect8[0], ws.key[0], ws.val[0], d)
     const bool h16 = scene.sh_dtype == 1;
     if (dbg) { if (h16) GSR_LAUNCH_PRE(true, true); else GSR_LAUNCH_PRE(true, false); }
     else     { if (h16) GSR_LAUNCH_PRE(false, true); else GSR_LAUNCH_PRE(false, false); }

@@ -173,6 +173,50 @@ def render_scene(input_dir: str, trained_model_path: str, scene_index: int = 0, 
     return renderer.Rasterizer(scene).render(cam, renderer.make_options(reference_compat=reference_compat, early_out_T=early_out_T))
 
 
+def _to_png_array(frame: torch.Tensor) -> np.ndarray:
+    """The reference's frame dump: (screen.transpose(1,0) * 255).astype(uint8), truncating (rasterize.py:449)."""
+    return (frame.cpu().numpy() * 255.0).astype(np.uint8)
+
+
+def render_progressive(input_dir: str, trained_model_path: str, output_path: str, scene_index: int = 0, scale_factor: int = 2,
+                       every: int = 1000, framerate: int = 20, device: str = "cuda") -> torch.Tensor:
+    """--generate_video (reference :427-429,:448-466): a PNG after gaussian number 1, 1001, 2001, ... of the draw
+    order (the reference saves when iteration_step % 1000 == 0, right after drawing), 2 s of padding frames that
+    repeat the LAST SAVED frame (the reference re-saves its stale `img`), then ffmpeg if it is installed.
+    Returns the final frame."""
+    import shutil
+    import subprocess
+
+    from PIL import Image
+
+    cam, _ = load_view(input_dir, scene_index, scale_factor)
+    ply_path = os.path.join(trained_model_path, "point_cloud/iteration_30000/point_cloud.ply")
+    R = renderer.Rasterizer(renderer.GaussianScene.from_ply(ply_path, device=device))
+    final = R.render(cam, renderer.make_options(draw_limit=2 ** 31 - 1))  # draw_limit > 0: counters follow the reference's order
+    n_drawn = int(R.last_stats["n_visible"])
+    img_dir = os.path.join(output_path, "images")
+    os.makedirs(img_dir, exist_ok=True)
+    img = None
+    for step in range(0, n_drawn, every):
+        frame = R.render(cam, renderer.make_options(draw_limit=step + 1))
+        img = Image.fromarray(_to_png_array(frame))
+        img.save(os.path.join(img_dir, f"image_iter_{str(step).zfill(7)}.png"))
+    if img is not None:
+        for i in range(1, 2 * framerate + 1):
+            img.save(os.path.join(img_dir, f"image_iter_{str(n_drawn + 1000 * i + 1).zfill(7)}.png"))
+    width, height = cam.width, cam.height
+    video_path = os.path.join(output_path, "video_render.mp4")
+    if shutil.which("ffmpeg"):
+        if os.path.exists(video_path):
+            os.remove(video_path)
+        pattern = os.path.join(img_dir, "image_iter_*.png")
+        subprocess.run(["ffmpeg", "-framerate", str(framerate), "-pattern_type", "glob", "-i", pattern, "-r", "10", "-vcodec", "libx264",
+                        "-s", f"{width - (width % 2)}x{height - (height % 2)}", "-pix_fmt", "yuv420p", video_path], check=True)
+    else:
+        logger.warning("ffmpeg not found: wrote the frames to %s, no video", img_dir)
+    return final
+
+
 @click.command()
 @click.option("--input_dir", type=str, default="")
 @click.option("--trained_model_path", type=str, default="")
@@ -184,11 +228,12 @@ def run_rasterization(input_dir: str, trained_model_path, output_path: Optional[
                       scale_factor: int = 2, generate_video: bool = False) -> None:
     """Same six options as the reference's command (:308-314).  Instead of a matplotlib window the frame is
     written to <output_path>/render.npy and render.png (uint8 truncation like the reference's frame dumps, :449)."""
-    if generate_video:
-        raise click.UsageError("--generate_video (progressive ffmpeg video) is not implemented in the HIP path")
     torch.set_num_threads(max(1, (os.cpu_count() or 2) - 1))
     logger.info("Fetching scenes from: %s", input_dir)
-    image = render_scene(input_dir, trained_model_path, scene_index, scale_factor)
+    if generate_video:
+        image = render_progressive(input_dir, trained_model_path, output_path, scene_index, scale_factor)
+    else:
+        image = render_scene(input_dir, trained_model_path, scene_index, scale_factor)
     if output_path:
         from PIL import Image
 

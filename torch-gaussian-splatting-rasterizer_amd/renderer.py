@@ -82,7 +82,7 @@ def make_camera(qvec, tvec, fx_full: float, fy_full: float, cam_width: int, cam_
 
 
 def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_row_begin: int = 0, tile_row_step: int = 1,
-                 output_layout: int = 0, no_footprint_cull: bool = False, blend_impl: int = 0) -> GsrOptions:
+                 output_layout: int = 0, no_footprint_cull: bool = False, blend_impl: int = 0, draw_limit: int = 0) -> GsrOptions:
     o = _lib.default_options()
     o.reference_compat = 1 if reference_compat else 0
     o.early_out_T = float(early_out_T)
@@ -91,6 +91,7 @@ def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_r
     o.output_layout = int(output_layout)
     o.no_footprint_cull = 1 if no_footprint_cull else 0
     o.blend_impl = int(blend_impl)
+    o.draw_limit = int(draw_limit)
     return o
 
 
