@@ -196,6 +196,23 @@ def test_progressive_render_matches_reference_draw_order(G, name, prefix):
     assert torch.equal(R.render(cam, G.renderer.make_options(draw_limit=n_drawn)), full)
 
 
+def test_very_wide_frame_uses_the_gathered_rect_path(G):
+    """More than 256 tiles per row: the tile rect no longer fits the packed 4 x u8 sort payload and is gathered by id."""
+    W, H = 4200, 40
+    cols = G.synthetic.mip360_like(40_000, 12)
+    for i in range(3):
+        cols[f"scale_{i}"] = (cols[f"scale_{i}"] + np.float32(1.0)).astype(np.float32)
+    p = G.synthetic.look_at_pose((0.0, -2.0, 0.1), (0, 0, 0), 1, "w.png")   # close: the foreground blob spans the full width
+    fx = G.synthetic.pinhole_focal(W, 100.0)
+    args = (p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H)
+    cam, ocam = G.renderer.make_camera(*args), G.orc.camera(*args)
+    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
+    img = R.render(cam).cpu().numpy()
+    oimg, _ = G.orc.render(G.utils.pack_gaussians(cols), ocam)
+    assert R.last_stats["n_pairs"] > 1000 and img[:, 4100:].any()     # content beyond tile column 256
+    assert_frames_close(img, oimg)
+
+
 def test_reference_screen_layout(G):
     g = load_golden("f2_small.npz")
     cam, _ = _cams(G, g)
