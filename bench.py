@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--gaussians", type=int, default=0, help="override the gaussian count (0 = the workload's)")
     ap.add_argument("--early-out-T", type=float, default=0.0)
     ap.add_argument("--blend-impl", type=int, default=0, help="0/1 vector-ALU blend (reference-grade), 2 matrix-pipe blend")
+    ap.add_argument("--overlap", action="store_true", help="two streams: run the SH colour pass under the sorts (measured slower)")
     ap.add_argument("--sh-half", action="store_true", help="store SH coefficients as fp16 (implied by --workload bicycle)")
     ap.add_argument("--camera", type=int, default=0)
     ap.add_argument("--camera-set", default="single", choices=["single", "all"],
@@ -152,7 +153,7 @@ def main():
     ncam = len(cams)
     plan = gdist.TileRowPlan(H, W, world)
     fg = gdist.FrameGather(plan, rank, dev)
-    R = renderer.Rasterizer(scene)
+    R = renderer.Rasterizer(scene, overlap=args.overlap)
     state1 = {"i": 0}
     if world == 1:  # no sharding: blend straight into the frame
         opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl)
@@ -225,7 +226,8 @@ def main():
                        "camera": args.camera if ncam == 1 else f"cycling over {ncam} cameras",
                        "sharding": f"tile rows interleaved over {world} GPU(s), RCCL gather to rank 0" if world > 1 else "none",
                        "reference_compat": True, "early_out_T": args.early_out_T, "sh_storage": "f16" if sh_half else "f32",
-                       "blend_impl": "mfma" if args.blend_impl == 2 else "valu"},
+                       "blend_impl": "mfma" if args.blend_impl == 2 else "valu",
+                       "streams": "2 (SH colour pass under the sorts)" if args.overlap else 1},
             "stats_rank0_shard": shard_stats,
         }
 

@@ -138,6 +138,16 @@ int gsr_workspace_bytes(int64_t n, int32_t width, int32_t height, int64_t max_pa
 int gsr_preprocess(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
                    size_t workspace_bytes, const GsrDebugOut *debug /* [host], may be NULL */, void *stream);
 
+/* Stage 1 in two halves, for callers that overlap them with stage 2: geometry decides visibility and writes everything
+ * but the colour (44 B read per gaussian); colour evaluates the SH of the gaussians geometry kept (192 B each).
+ * Nothing before gsr_blend reads the colour, so gsr_preprocess_color may run on a SECOND stream concurrently with
+ * gsr_bin_sort (small, latency-bound launches): order it after gsr_preprocess_geometry and before gsr_blend with events.
+ * gsr_preprocess_geometry + gsr_preprocess_color == gsr_preprocess, bit for bit. */
+int gsr_preprocess_geometry(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
+                            size_t workspace_bytes, void *stream);
+int gsr_preprocess_color(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
 /* Stage 2 — depth order (rasterize.py:424-425, ties broken by gaussian index) and 16x16 tile binning:
  * radix sort of the visible gaussians by depth, pair emission in depth order, stable radix sort by tile,
  * per-tile [begin,end) ranges.  Needs gsr_preprocess on the same workspace first. */

@@ -213,6 +213,18 @@ def test_very_wide_frame_uses_the_gathered_rect_path(G):
     assert_frames_close(img, oimg)
 
 
+def test_split_stage1_on_two_streams_is_bit_identical(G):
+    """gsr_preprocess_geometry + gsr_preprocess_color (second stream, under the sorts) == the fused gsr_preprocess."""
+    cols, cam, _ = _medium(G)
+    scene = G.renderer.GaussianScene.from_columns(cols)
+    a = G.renderer.Rasterizer(scene, overlap=False).render(cam)
+    R = G.renderer.Rasterizer(scene, overlap=True)
+    for _ in range(3):
+        assert torch.equal(R.render(cam), a)
+    half = G.renderer.GaussianScene.from_columns(cols, sh_half=True)
+    assert torch.equal(G.renderer.Rasterizer(half, overlap=True).render(cam), G.renderer.Rasterizer(half, overlap=False).render(cam))
+
+
 def test_reference_screen_layout(G):
     g = load_golden("f2_small.npz")
     cam, _ = _cams(G, g)

@@ -50,6 +50,7 @@ size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max
     for (int b = 0; b < 2; ++b) ws->key[b] = static_cast<uint32_t *>(take(4 * nn));
     for (int b = 0; b < 2; ++b) ws->val[b] = static_cast<uint32_t *>(take(4 * nn));
     for (int b = 0; b < 2; ++b) ws->rect8[b] = static_cast<uint32_t *>(take(4 * nn));
+    ws->vis = static_cast<unsigned char *>(take(nn));
     ws->blk_sum = static_cast<uint32_t *>(
         take(4 * ((std::max(nn, (size_t)ws->tiles_x * ws->tiles_y) + EMIT_THREADS - 1) / EMIT_THREADS + 1)));
     ws->hist = static_cast<uint32_t *>(take(4 * 256 * (size_t)ws->hist_blocks));
@@ -201,7 +202,8 @@ static int check_scene(const GsrScene *sc)
 }
 
 static int preprocess_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
-                           size_t workspace_bytes, const GsrDebugOut *debug, void *stream, bool keep_batch_words);
+                           size_t workspace_bytes, const GsrDebugOut *debug, void *stream, bool keep_batch_words,
+                           bool with_color = true);
 
 int gsr_preprocess(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
                    size_t workspace_bytes, const GsrDebugOut *debug, void *stream)
@@ -210,7 +212,8 @@ int gsr_preprocess(const GsrScene *scene, const GsrCamera *cam, const GsrOptions
 }
 
 static int preprocess_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
-                           size_t workspace_bytes, const GsrDebugOut *debug, void *stream, bool keep_batch_words)
+                           size_t workspace_bytes, const GsrDebugOut *debug, void *stream, bool keep_batch_words,
+                           bool with_color)
 {
     int rc = check_scene(scene);
     if (rc) return rc;
@@ -221,7 +224,24 @@ static int preprocess_impl(const GsrScene *scene, const GsrCamera *cam, const Gs
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     GSR_HIP(hipMemsetAsync(ws.ctrl, 0, keep_batch_words ? offsetof(FrameCtrl, batch_overflow) : sizeof(FrameCtrl), s));
-    return launch_preprocess(*scene, *cam, *opts, ws, debug, s);
+    return launch_preprocess(*scene, *cam, *opts, ws, debug, with_color, s);
+}
+
+int gsr_preprocess_geometry(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
+                            size_t workspace_bytes, void *stream)
+{
+    return preprocess_impl(scene, cam, opts, workspace, workspace_bytes, nullptr, stream, false, false);
+}
+
+int gsr_preprocess_color(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
+                         size_t workspace_bytes, void *stream)
+{
+    int rc = check_scene(scene);
+    if (rc) return rc;
+    Workspace ws;
+    rc = check_frame(scene->n, cam, opts, 0, workspace, workspace_bytes, &ws);
+    if (rc) return rc;
+    return launch_color(*scene, *cam, ws, static_cast<hipStream_t>(stream));
 }
 
 int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs, void *workspace,

@@ -44,6 +44,7 @@ struct Workspace {
     FrameCtrl *ctrl;
     GaussRec *rec;        // [n]
     ushort4 *rect;        // [n]   tile rect {tx0, ty0, tx1, ty1} (exclusive upper), after footprint refinement
+    unsigned char *vis;   // [n]   1 = kept by the geometry pass (only written when stage 1 is split)
     uint32_t *rect8[2];   // [n]   the same rect packed x0 | y0<<8 | (x1-1)<<16 | (y1-1)<<24; rides through the depth
                           //       sort as a second payload when the tile grid fits 8 bits (frames up to 4096 px)
     uint32_t *key[2];     // [n]   depth keys (ping-pong)
@@ -76,7 +77,8 @@ int hip_fail(hipError_t e, const char *what);
 
 // ---- kernels' host launchers (each returns GSR_OK / GSR_ERR_HIP) --------------------------------
 int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws,
-                      const GsrDebugOut *dbg, hipStream_t s);
+                      const GsrDebugOut *dbg, bool with_color, hipStream_t s);
+int launch_color(const GsrScene &scene, const GsrCamera &cam, const Workspace &ws, hipStream_t s);
 int launch_sh_to_rgb(int64_t n, const float *means, const float *sh, const float cc[3], int degree, float *rgb, hipStream_t s);
 int launch_cov3d(int64_t n, const float *log_scales, const float *quats, float *out, hipStream_t s);
 int launch_project(int64_t n, const float *means, const float w2c[16], float *out, hipStream_t s);

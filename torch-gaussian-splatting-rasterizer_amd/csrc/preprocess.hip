@@ -23,8 +23,8 @@ struct Cam {
     int W, H;
 };
 
-template <bool DEBUG, bool SH16>
-__global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, GaussRec *__restrict__ rec,
+template <bool DEBUG, bool SH16, bool WITH_COLOR>
+__global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, unsigned char *__restrict__ vis, GaussRec *__restrict__ rec,
                                                          ushort4 *__restrict__ rect, uint32_t *__restrict__ rect8, uint32_t *__restrict__ depth_key,
                                                          uint32_t *__restrict__ ident, GsrDebugOut dbg)
 {
@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
     }
 
     float rgb[3] = {0.f, 0.f, 0.f};
-    if (visible || (DEBUG && dbg.rgb)) {
+    if (!WITH_COLOR) vis[i] = visible ? 1 : 0;  // the colour pass (gsr_preprocess_color) runs later, possibly on another stream
+    if (WITH_COLOR && (visible || (DEBUG && dbg.rgb))) {
         float sh[48];
         if (SH16) load_sh48_f16(sc.sh, i, sh);
         else load_sh48(reinterpret_cast<const float *>(sc.sh), i, sh);
@@ -184,6 +185,27 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
     rec[i] = r;
 }
 
+// Second half of stage 1 when it is split (gsr_preprocess_geometry + gsr_preprocess_color): sh_to_rgb
+// (spherical_harmonics.py:27-73) of every gaussian the geometry pass kept, rec[i].q2.yzw <- rgb.  Nothing before the
+// blend reads the colour, so the caller may run this on a second stream while the depth sort and the binning — small,
+// latency-bound launches that leave the chip mostly idle — run on the first.
+template <bool SH16>
+__global__ __launch_bounds__(256) void color_kernel(GsrScene sc, float cx, float cy, float cz, const unsigned char *__restrict__ vis,
+                                                    GaussRec *__restrict__ rec)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sc.n || !vis[i]) return;
+    float sh[48];
+    if (SH16) load_sh48_f16(sc.sh, i, sh);
+    else load_sh48(reinterpret_cast<const float *>(sc.sh), i, sh);
+    const float p[3] = {sc.means[3 * i], sc.means[3 * i + 1], sc.means[3 * i + 2]};
+    const float cc[3] = {cx, cy, cz};
+    float rgb[3];
+    sh_eval(p, sh, cc, sc.sh_degree, rgb);  // rasterize.py:368
+    float *q2 = reinterpret_cast<float *>(&rec[i].q2);
+    q2[1] = rgb[0]; q2[2] = rgb[1]; q2[3] = rgb[2];
+}
+
 static Cam make_cam(const GsrCamera &c)
 {
     Cam k;
@@ -195,7 +217,7 @@ static Cam make_cam(const GsrCamera &c)
 }
 
 int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws,
-                      const GsrDebugOut *dbg, hipStream_t s)
+                      const GsrDebugOut *dbg, bool with_color, hipStream_t s)
 {
     if (scene.n <= 0) return GSR_OK;
     const unsigned grid = (unsigned)((scene.n + 255) / 256);
@@ -203,13 +225,27 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
     GsrDebugOut d;
     memset(&d, 0, sizeof d);
     if (dbg) d = *dbg;
-#define GSR_LAUNCH_PRE(DBG, H16)                                                                                             \
-    hipLaunchKernelGGL((preprocess_kernel<DBG, H16>), dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat,            \
-                       opts.no_footprint_cull, opts.tile_row_begin, opts.tile_row_step < 1 ? 1 : opts.tile_row_step, opts.draw_limit > 0 ? 1 : 0, ws.rec, ws.rect, ws.rect8[0], ws.key[0], ws.val[0], d)
+#define GSR_LAUNCH_PRE(DBG, H16, COL)                                                                                        \
+    hipLaunchKernelGGL((preprocess_kernel<DBG, H16, COL>), dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat,       \
+                       opts.no_footprint_cull, opts.tile_row_begin, opts.tile_row_step < 1 ? 1 : opts.tile_row_step,          \
+                       opts.draw_limit > 0 ? 1 : 0, ws.vis, ws.rec, ws.rect, ws.rect8[0], ws.key[0], ws.val[0], d)
     const bool h16 = scene.sh_dtype == 1;
-    if (dbg) { if (h16) GSR_LAUNCH_PRE(true, true); else GSR_LAUNCH_PRE(true, false); }
-    else     { if (h16) GSR_LAUNCH_PRE(false, true); else GSR_LAUNCH_PRE(false, false); }
+    if (!with_color) GSR_LAUNCH_PRE(false, false, false);
+    else if (dbg) { if (h16) GSR_LAUNCH_PRE(true, true, true); else GSR_LAUNCH_PRE(true, false, true); }
+    else          { if (h16) GSR_LAUNCH_PRE(false, true, true); else GSR_LAUNCH_PRE(false, false, true); }
 #undef GSR_LAUNCH_PRE
+    GSR_HIP(hipGetLastError());
+    return GSR_OK;
+}
+
+int launch_color(const GsrScene &scene, const GsrCamera &cam, const Workspace &ws, hipStream_t s)
+{
+    if (scene.n <= 0) return GSR_OK;
+    const unsigned grid = (unsigned)((scene.n + 255) / 256);
+    if (scene.sh_dtype == 1)
+        hipLaunchKernelGGL(color_kernel<true>, dim3(grid), dim3(256), 0, s, scene, cam.cam_center[0], cam.cam_center[1], cam.cam_center[2], ws.vis, ws.rec);
+    else
+        hipLaunchKernelGGL(color_kernel<false>, dim3(grid), dim3(256), 0, s, scene, cam.cam_center[0], cam.cam_center[1], cam.cam_center[2], ws.vis, ws.rec);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }
