@@ -112,6 +112,8 @@ class PlyData:
             for el in self.elements:
                 head.append(f"element {el.name} {len(el)}")
                 for p in el.properties:
+                    if not p or any(ch.isspace() for ch in p):
+                        raise ValueError(f"PLY property names are whitespace-delimited header tokens: {p!r} cannot be written")
                     kind = el.data.dtype[p]
                     ply_t = {"f4": "float", "f8": "double", "i4": "int", "u1": "uchar", "i2": "short",
                              "u2": "ushort", "u4": "uint", "i1": "char"}[kind.str[1:]]

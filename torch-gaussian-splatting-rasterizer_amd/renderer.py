@@ -149,6 +149,8 @@ class Rasterizer:
                 torch.empty(shape, dtype=torch.float32, device=self.scene.device)
         elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or not out.is_cuda:
             raise ValueError(f"out must be a contiguous float32 CUDA tensor of shape {shape}")
+        if out.numel() == 0:  # a shard that owns no tile row (more ranks than tile rows): nothing to render
+            return out
         sc = self.scene.c_struct()
         tptr = final_T.data_ptr() if final_T is not None else None
         if not self.overlap:
