@@ -57,7 +57,9 @@ size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max
     for (int b = 0; b < 2; ++b) ws->pkey[b] = static_cast<uint32_t *>(take(4 * np));
     for (int b = 0; b < 2; ++b) ws->pval[b] = static_cast<uint32_t *>(take(4 * np));
     ws->ranges = static_cast<uint2 *>(take(sizeof(uint2) * (size_t)ws->tiles_x * ws->tiles_y));
-    ws->tile_order = static_cast<int *>(take(sizeof(int) * 8 * (size_t)((ws->tiles_y + 7) / 8) * ws->tiles_x));
+    const size_t order_slots = 8 * (size_t)((ws->tiles_y + 7) / 8) * ws->tiles_x;
+    ws->tile_order = static_cast<int *>(take(sizeof(int) * order_slots));
+    ws->blend_stats = static_cast<uint32_t *>(take(sizeof(uint32_t) * BLEND_STAT_WORDS * order_slots));
     ws->pair_off = nullptr;
     ws->bytes = off;
     return off;
@@ -327,6 +329,10 @@ int gsr_read_stats(const void *workspace, size_t workspace_bytes, GsrStats *out,
     if (!workspace || !out || workspace_bytes < sizeof(FrameCtrl)) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
     static_assert(sizeof(GsrStats) == 40, "GsrStats is the head of FrameCtrl");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    {  // total the blend's per-workgroup counters; the kernel finds them through the offsets kept in FrameCtrl
+        const int rc = launch_blend_stats(static_cast<FrameCtrl *>(const_cast<void *>(workspace)), workspace_bytes, s);
+        if (rc != GSR_OK) return rc;
+    }
     GSR_HIP(hipMemcpyAsync(out, workspace, sizeof(GsrStats), hipMemcpyDeviceToHost, s));
     GSR_HIP(hipStreamSynchronize(s));
     if (out->overflow) {

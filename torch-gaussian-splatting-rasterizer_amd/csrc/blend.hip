@@ -61,7 +61,7 @@ __device__ __forceinline__ void blend_one(const float2 g, const float4 c, const 
 // Also leaves the longest list length in ctrl (stats).
 __global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict__ ranges, FrameCtrl *ctrl, int tiles_x,
                                                          int row_begin, int row_step, int rows, int slots_per_group,
-                                                         int *__restrict__ order)
+                                                         int *__restrict__ order, uint32_t stats_off)
 {
     constexpr int NB = 256;
     __shared__ uint32_t bucket_cnt[NB];
@@ -95,6 +95,10 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, d, 64));
     if ((tid & 63) == 0 && longest > 0) atomicMax(&ctrl->max_list_len, longest);
+    if (g == 0 && tid == 0) {  // where gsr_read_stats finds the counters of the blend launched next
+        ctrl->stats_off = stats_off;
+        ctrl->stats_slots = 8u * (uint32_t)slots_per_group;
+    }
 }
 
 __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
@@ -105,10 +109,14 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
     __shared__ int s_done;
 
     const int tile = a.order[blockIdx.x];
-    if (tile < 0) return;  // uniform
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *stat = a.stats + (size_t)blockIdx.x * BLEND_STAT_WORDS;
+    if (tile < 0) {  // uniform: empty launch slot
+        if (tid < 5) stat[tid] = 0;
+        return;
+    }
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qx = tx * 16 + (wave & 1) * 8, qy = ty * 16 + (wave >> 1) * 8;
     const int px = qx + (lane & 7), py = qy + (lane >> 3);
     const float fpx = (float)px, fpy = (float)py;
@@ -168,8 +176,8 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
         }
     }
 
-    if (lane == 0 && evaluated) atomicAdd(&a.ctrl->wave_entries, (unsigned long long)evaluated);
-    if (tid == 0 && fetched) atomicAdd(&a.ctrl->fetched_entries, (unsigned long long)fetched);
+    if (lane == 0) stat[wave] = evaluated;
+    if (tid == 0) stat[4] = fetched;
     if (px < a.W && py < a.H) {
         const bool drawn = px < a.xlim && py < a.ylim;  // Q1: last column / row stay black, T stays 1
         const float r = drawn ? Cr : 0.0f, g = drawn ? Cg : 0.0f, b = drawn ? Cb : 0.0f;
@@ -196,7 +204,7 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     a.rec = ws.rec;
     a.out = out_image;
     a.out_T = out_T;
-    a.ctrl = ws.ctrl;
+    a.stats = ws.blend_stats;
     a.W = cam.width; a.H = cam.height;
     a.xlim = opts.reference_compat ? cam.width - 1 : cam.width;
     a.ylim = opts.reference_compat ? cam.height - 1 : cam.height;
@@ -211,9 +219,47 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     const int slots_per_group = rows_per_xcd * a.tiles_x;
     a.order = ws.tile_order;
     hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(256), 0, s, ws.ranges, ws.ctrl, a.tiles_x, a.row_begin, a.row_step, a.rows,
-                       slots_per_group, ws.tile_order);
+                       slots_per_group, ws.tile_order,
+                       (uint32_t)(reinterpret_cast<const char *>(ws.blend_stats) - reinterpret_cast<const char *>(ws.ctrl)));
     if (opts.blend_impl == 2) return launch_blend_mfma(a, 8u * (unsigned)slots_per_group, s);
     hipLaunchKernelGGL(blend_kernel, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
+    GSR_HIP(hipGetLastError());
+    return GSR_OK;
+}
+
+// gsr_read_stats: total the per-workgroup counters of the last blend into FrameCtrl.  One workgroup, no atomics;
+// the layout comes from FrameCtrl itself because gsr_read_stats is handed nothing but the workspace.
+__global__ __launch_bounds__(1024) void blend_stats_kernel(FrameCtrl *ctrl, size_t workspace_bytes)
+{
+    __shared__ unsigned long long part[2][16];
+    const uint32_t off = ctrl->stats_off, slots = ctrl->stats_slots;
+    unsigned long long ev = 0, fe = 0;
+    if (off >= sizeof(FrameCtrl) && (size_t)off + (size_t)slots * BLEND_STAT_WORDS * 4 <= workspace_bytes) {
+        const uint32_t *st = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(ctrl) + off);
+        for (uint32_t i = threadIdx.x; i < slots; i += 1024) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(st + (size_t)i * BLEND_STAT_WORDS);
+            ev += (unsigned long long)v.x + v.y + v.z + v.w;
+            fe += st[(size_t)i * BLEND_STAT_WORDS + 4];
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        ev += __shfl_xor(ev, d, 64);
+        fe += __shfl_xor(fe, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = ev; part[1][threadIdx.x >> 6] = fe; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ev = fe = 0;
+        for (int w = 0; w < 16; ++w) { ev += part[0][w]; fe += part[1][w]; }
+        ctrl->wave_entries = ev;
+        ctrl->fetched_entries = fe;
+    }
+}
+
+int launch_blend_stats(FrameCtrl *ctrl, size_t workspace_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL(blend_stats_kernel, dim3(1), dim3(1024), 0, s, ctrl, workspace_bytes);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

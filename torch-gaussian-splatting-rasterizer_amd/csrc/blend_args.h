@@ -10,7 +10,7 @@ struct BlendArgs {
     const GaussRec *rec;
     float *out;
     float *out_T;
-    FrameCtrl *ctrl;
+    uint32_t *stats;      // [launch slots][BLEND_STAT_WORDS]
     const int *order;     // tile launch order (tile_order_kernel), -1 = empty slot
     int W, H;
     int xlim, ylim;       // pixels x < xlim, y < ylim are drawn (W-1/H-1 in reference_compat: Q1)

@@ -107,10 +107,13 @@ __global__ __launch_bounds__(256, 4) void blend_mfma_kernel(BlendArgs a)
     __shared__ int s_done;
 
     const int tile = a.order[blockIdx.x];
-    if (tile < 0) return;  // uniform
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tile < 0) {  // uniform: empty launch slot
+        if (tid < 5) a.stats[(size_t)blockIdx.x * BLEND_STAT_WORDS + tid] = 0;
+        return;
+    }
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qx = tx * 16 + (wave & 1) * 8, qy = ty * 16 + (wave >> 1) * 8;
     const int px = qx + (lane & 7), py = qy + (lane >> 3);  // the pixel this lane finally stores
     const float qx0 = (float)qx, qx1 = (float)(qx + 7), qy0 = (float)qy, qy1 = (float)(qy + 7);
@@ -215,8 +218,8 @@ __global__ __launch_bounds__(256, 4) void blend_mfma_kernel(BlendArgs a)
     const float r1 = st1.Cr + __shfl_xor(st1.Cr, 32, 64), g1 = st1.Cg + __shfl_xor(st1.Cg, 32, 64), bl1 = st1.Cb + __shfl_xor(st1.Cb, 32, 64);
     const float Cr = hsel ? r1 : r0, Cg = hsel ? g1 : g0, Cb = hsel ? bl1 : bl0, T = hsel ? st1.T : st0.T;
 
-    if (lane == 0 && evaluated) atomicAdd(&a.ctrl->wave_entries, (unsigned long long)evaluated);
-    if (tid == 0 && fetched) atomicAdd(&a.ctrl->fetched_entries, (unsigned long long)fetched);
+    if (lane == 0) a.stats[(size_t)blockIdx.x * BLEND_STAT_WORDS + wave] = evaluated;
+    if (tid == 0) a.stats[(size_t)blockIdx.x * BLEND_STAT_WORDS + 4] = fetched;
     if (px < a.W && py < a.H) {
         const bool drawn = px < a.xlim && py < a.ylim;  // Q1: last column / row stay black, T stays 1
         const float r = drawn ? Cr : 0.0f, g = drawn ? Cg : 0.0f, b = drawn ? Cb : 0.0f;

@@ -19,12 +19,15 @@ struct FrameCtrl {
     uint32_t overflow;
     uint32_t max_list_len;
     uint32_t n_slots;       // min(D, max_pairs): pair slots written by the emit kernel
-    unsigned long long wave_entries;  // (quadrant, entry) pairs evaluated by the blend
-    unsigned long long fetched_entries;  // list entries staged by the blend
+    unsigned long long wave_entries;  // (quadrant, entry) pairs evaluated by the blend   } totals of blend_stats[], filled in
+    unsigned long long fetched_entries;  // list entries staged by the blend              } by gsr_read_stats
     uint32_t digit_tot[256]; // per-digit totals of the radix pass in flight
+    uint32_t stats_off;      // byte offset of blend_stats[] from this struct, and the number of launch slots the last
+    uint32_t stats_slots;    // blend filled (tile_order_kernel writes both; 0 = no blend since the frame was reset)
     uint32_t batch_overflow; // sticky across the views of gsr_render_batch (not cleared per frame)
     uint32_t batch_need;     // largest D seen in the batch
 };
+constexpr int BLEND_STAT_WORDS = 8;  // per launch slot: [0..3] evaluated entries of waves 0..3, [4] staged entries
 
 // Per-gaussian record consumed by pair emission and the blend (48 B, three 16-B loads):
 //   q0 = {mean_x, mean_y, -B/(2C), -B/(2A)}   the two ratios locate the edge maxima in footprint.h
@@ -56,6 +59,8 @@ struct Workspace {
     uint32_t *pval[2];    // [max_pairs] gaussian ids
     uint2 *ranges;        // [tiles]
     int *tile_order;      // [8 * ceil(tiles_y/8) * tiles_x] blend launch order
+    uint32_t *blend_stats; // [tile_order slots][BLEND_STAT_WORDS] per-workgroup counters: plain stores, no atomics (40 k
+                          // same-address atomics per frame put a 0.45 ms floor under the blend kernel)
     int64_t n;
     int64_t max_pairs;
     int tiles_x, tiles_y;
@@ -103,6 +108,7 @@ inline bool rect_fits_8bit(const Workspace &ws) { return ws.tiles_x <= 256 && ws
 int launch_tile_ranges(const Workspace &ws, int pair_buf, hipStream_t s);
 int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int pair_buf, float *out_image,
                  float *out_T, hipStream_t s);
+int launch_blend_stats(FrameCtrl *ctrl, size_t workspace_bytes, hipStream_t s);
 
 // which pair buffer holds the tile-sorted pairs, given the tile count (passes parity)
 int tile_sort_passes(int tiles);
