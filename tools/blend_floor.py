@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--workload", default="garden")
     ap.add_argument("--gaussians", type=int, default=0)
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--ab-rounds", type=int, default=0, help="only compare the two blend implementations, interleaved")
     a = ap.parse_args()
 
     import bench
@@ -54,6 +55,13 @@ def main():
               f"fetched/launch {st['fetched_entries'] / 1e6:7.2f} M   pairs {st['n_pairs'] / 1e6:6.2f} M", flush=True)
 
     mk = renderer.make_options
+    if a.ab_rounds:
+        for _ in range(a.ab_rounds):
+            time_blend("exact, valu", mk(), mk())
+            time_blend("exact, mfma", mk(), mk(blend_impl=2))
+            time_blend("early_out_T=1e-4, valu", mk(), mk(early_out_T=1e-4))
+            time_blend("early_out_T=1e-4, mfma", mk(), mk(early_out_T=1e-4, blend_impl=2))
+        return
     time_blend("exact", mk(), mk())
     for T in (1e-6, 1e-4, 1e-2, 0.5):
         time_blend(f"early_out_T={T:g}", mk(), mk(early_out_T=T))

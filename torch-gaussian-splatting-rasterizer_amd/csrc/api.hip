@@ -225,8 +225,9 @@ static int preprocess_impl(const GsrScene *scene, const GsrCamera *cam, const Gs
     rc = check_frame(scene->n, cam, opts, 0, workspace, workspace_bytes, &ws);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    GSR_HIP(hipMemsetAsync(ws.ctrl, 0, keep_batch_words ? offsetof(FrameCtrl, batch_overflow) : sizeof(FrameCtrl), s));
-    return launch_preprocess(*scene, *cam, *opts, ws, debug, with_color, s);
+    static_assert(sizeof(FrameCtrl) % 4 == 0 && offsetof(FrameCtrl, batch_overflow) % 4 == 0, "FrameCtrl is cleared by words");
+    const int reset_words = (int)((keep_batch_words ? offsetof(FrameCtrl, batch_overflow) : sizeof(FrameCtrl)) / 4);
+    return launch_preprocess(*scene, *cam, *opts, ws, debug, with_color, reset_words, s);
 }
 
 int gsr_preprocess_geometry(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,

@@ -25,7 +25,10 @@
 
 namespace gsr {
 
-constexpr uint32_t CULL_MIN_TILES = 8;
+#ifndef GSR_CULL_MIN_TILES
+#define GSR_CULL_MIN_TILES 8
+#endif
+constexpr uint32_t CULL_MIN_TILES = GSR_CULL_MIN_TILES;
 
 struct Shard {
     int begin, step;
@@ -84,41 +87,63 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t
     if (threadIdx.x == 0) blk_sum[blockIdx.x] = total;
 }
 
-// Single workgroup (1024 threads): exclusive scan of blk_sum[0..nblk) in place; totals into ctrl.
+// Single workgroup (1024 threads): exclusive scan of blk_sum[0..nblk) in place; totals into ctrl.  Sixteen
+// consecutive sums per thread (four 16-B loads), so a 6 M-gaussian frame is one trip: serial scan in registers,
+// wave scan, 16 wave totals through LDS.  64-bit partials so that a D beyond 2^32 is still caught as overflow.
 __global__ __launch_bounds__(1024) void pair_scan_kernel(uint32_t *__restrict__ blk_sum, int nblk_bound, FrameCtrl *ctrl,
                                                          uint32_t max_pairs)
 {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t s_carry;
+    constexpr int PER = 16;
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n = ctrl->n_visible;
     const int nblk = min(nblk_bound, (int)((n + EMIT_THREADS - 1) / EMIT_THREADS));
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    unsigned long long grand = 0;  // 64-bit so that a D beyond 2^32 is still caught as overflow
-    for (int base = 0; base < nblk; base += 1024) {
-        const int i = base + tid;
-        const uint32_t v = i < nblk ? blk_sum[i] : 0u;
-        const uint32_t incl = wave_incl_scan(v);
+    unsigned long long grand = 0;
+    for (int base = 0; base < nblk; base += 1024 * PER) {
+        const int i0 = base + tid * PER;
+        uint32_t v[PER];
+        if (i0 + PER <= nblk) {
+#pragma unroll
+            for (int q = 0; q < PER / 4; ++q) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(blk_sum + i0 + 4 * q);
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) v[j] = i0 + j < nblk ? blk_sum[i0 + j] : 0u;
+        }
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) mine += v[j];
+        unsigned long long incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
         if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        uint32_t wbase = 0, tot = 0;
+        unsigned long long wbase = 0, tot = 0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) {
-            const uint32_t s = wsum[w];
+            const unsigned long long s = wsum[w];
             if (w < wave) wbase += s;
             tot += s;
         }
-        const uint32_t carry = s_carry;
+        const unsigned long long carry = s_carry;
         // saturating: once the running total passes max_pairs the exact value no longer matters
-        const unsigned long long ex = (unsigned long long)carry + wbase + (incl - v);
-        if (i < nblk) blk_sum[i] = ex > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ex;
+        unsigned long long ex = carry + wbase + (incl - mine);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (i0 + j < nblk) blk_sum[i0 + j] = ex > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ex;
+            ex += v[j];
+        }
         grand += tot;
         __syncthreads();
-        if (tid == 0) {
-            const unsigned long long c = (unsigned long long)carry + tot;
-            s_carry = c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c;
-        }
+        if (tid == 0) s_carry = carry + tot;
         __syncthreads();
     }
     if (tid == 0) {
@@ -200,13 +225,29 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t *__restrict__ pkey, const FrameCtrl *ctrl,
                                                           uint2 *__restrict__ ranges, int n_tiles)
 {
+    // four keys per thread from one 16-B load; only the two keys flanking the group are read a second time
     const uint32_t n = ctrl->n_pairs;
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t k = pkey[i];
-        if (k >= (uint32_t)n_tiles) continue;  // cannot happen; keeps a corrupt key from writing out of bounds
-        if (i == 0 || pkey[i - 1] != k) ranges[k].x = i;
-        if (i + 1 == n || pkey[i + 1] != k) ranges[k].y = i + 1;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; 4ull * t < n; t += stride) {
+        const uint32_t i = 4u * t;
+        uint32_t k[6];  // k[0] = key before the group, k[1..4] = the group, k[5] = key after it
+        if (i + 4 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(pkey + i);
+            k[1] = v.x; k[2] = v.y; k[3] = v.z; k[4] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) k[1 + j] = i + j < n ? pkey[i + j] : KEY_INVALID;
+        }
+        k[0] = i > 0 ? pkey[i - 1] : KEY_INVALID;            // KEY_INVALID never survives pass 0: always a boundary
+        k[5] = i + 4 < n ? pkey[i + 4] : KEY_INVALID;
+#pragma unroll
+        for (int j = 1; j <= 4; ++j) {
+            const uint32_t idx = i + (uint32_t)(j - 1);
+            const uint32_t key = k[j];
+            if (idx >= n || key >= (uint32_t)n_tiles) continue;  // the second test cannot fail; it keeps a corrupt key in bounds
+            if (k[j - 1] != key) ranges[key].x = idx;
+            if (idx + 1 == n || k[j + 1] != key) ranges[key].y = idx + 1;
+        }
     }
 }
 
@@ -258,7 +299,7 @@ int launch_tile_ranges(const Workspace &ws, int pair_buf, hipStream_t s)
         return GSR_OK;
     }
     if (ws.max_pairs <= 0) return GSR_OK;
-    const int grid = (int)std::min<int64_t>((ws.max_pairs + 255) / 256, 4096);
+    const int grid = (int)std::min<int64_t>((ws.max_pairs + 1023) / 1024, 8192);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(grid), dim3(256), 0, s, ws.pkey[pair_buf], ws.ctrl, ws.ranges, n_tiles);
     GSR_HIP(hipGetLastError());
     return GSR_OK;

@@ -82,7 +82,7 @@ int hip_fail(hipError_t e, const char *what);
 
 // ---- kernels' host launchers (each returns GSR_OK / GSR_ERR_HIP) --------------------------------
 int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws,
-                      const GsrDebugOut *dbg, bool with_color, hipStream_t s);
+                      const GsrDebugOut *dbg, bool with_color, int ctrl_reset_words, hipStream_t s);
 int launch_color(const GsrScene &scene, const GsrCamera &cam, const Workspace &ws, hipStream_t s);
 int launch_sh_to_rgb(int64_t n, const float *means, const float *sh, const float cc[3], int degree, float *rgb, hipStream_t s);
 int launch_cov3d(int64_t n, const float *log_scales, const float *quats, float *out, hipStream_t s);

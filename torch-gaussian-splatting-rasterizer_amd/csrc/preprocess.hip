@@ -26,8 +26,13 @@ struct Cam {
 template <bool DEBUG, bool SH16, bool WITH_COLOR>
 __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, unsigned char *__restrict__ vis, GaussRec *__restrict__ rec,
                                                          ushort4 *__restrict__ rect, uint32_t *__restrict__ rect8, uint32_t *__restrict__ depth_key,
-                                                         uint32_t *__restrict__ ident, GsrDebugOut dbg)
+                                                         uint32_t *__restrict__ ident, GsrDebugOut dbg,
+                                                         uint32_t *__restrict__ ctrl_words, int ctrl_reset_words)
 {
+    // frame reset: nothing in this kernel reads FrameCtrl and every later kernel of the frame is stream-ordered behind it,
+    // so workgroup 0 clears the counters here (a hipMemsetAsync costs two blit kernels and a dispatch bubble, ~20 us)
+    if (blockIdx.x == 0)
+        for (int w = threadIdx.x; w < ctrl_reset_words; w += 256) ctrl_words[w] = 0u;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sc.n) return;
     ident[i] = (uint32_t)i;
@@ -217,9 +222,12 @@ static Cam make_cam(const GsrCamera &c)
 }
 
 int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws,
-                      const GsrDebugOut *dbg, bool with_color, hipStream_t s)
+                      const GsrDebugOut *dbg, bool with_color, int ctrl_reset_words, hipStream_t s)
 {
-    if (scene.n <= 0) return GSR_OK;
+    if (scene.n <= 0) {  // no kernel to carry the frame reset
+        GSR_HIP(hipMemsetAsync(ws.ctrl, 0, 4 * (size_t)ctrl_reset_words, s));
+        return GSR_OK;
+    }
     const unsigned grid = (unsigned)((scene.n + 255) / 256);
     const Cam k = make_cam(cam);
     GsrDebugOut d;
@@ -228,7 +236,8 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
 #define GSR_LAUNCH_PRE(DBG, H16, COL)                                                                                        \
     hipLaunchKernelGGL((preprocess_kernel<DBG, H16, COL>), dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat,       \
                        opts.no_footprint_cull, opts.tile_row_begin, opts.tile_row_step < 1 ? 1 : opts.tile_row_step,          \
-                       opts.draw_limit > 0 ? 1 : 0, ws.vis, ws.rec, ws.rect, ws.rect8[0], ws.key[0], ws.val[0], d)
+                       opts.draw_limit > 0 ? 1 : 0, ws.vis, ws.rec, ws.rect, ws.rect8[0], ws.key[0], ws.val[0], d,                     \
+                       reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words)
     const bool h16 = scene.sh_dtype == 1;
     if (!with_color) GSR_LAUNCH_PRE(false, false, false);
     else if (dbg) { if (h16) GSR_LAUNCH_PRE(true, true, true); else GSR_LAUNCH_PRE(true, false, true); }
