@@ -26,8 +26,8 @@ struct Cam {
 template <bool DEBUG, bool SH16, bool WITH_COLOR>
 __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, unsigned char *__restrict__ vis, GaussRec *__restrict__ rec,
                                                          ushort4 *__restrict__ rect, uint32_t *__restrict__ rect8, uint32_t *__restrict__ depth_key,
-                                                         uint32_t *__restrict__ ident, GsrDebugOut dbg,
-                                                         uint32_t *__restrict__ ctrl_words, int ctrl_reset_words)
+                                                         GsrDebugOut dbg,
+                                                         uint32_t *__restrict__ ctrl_words, int ctrl_reset_words, int packed_rect)
 {
     // frame reset: nothing in this kernel reads FrameCtrl and every later kernel of the frame is stream-ordered behind it,
     // so workgroup 0 clears the counters here (a hipMemsetAsync costs two blit kernels and a dispatch bubble, ~20 us)
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
         for (int w = threadIdx.x; w < ctrl_reset_words; w += 256) ctrl_words[w] = 0u;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sc.n) return;
-    ident[i] = (uint32_t)i;
+    // (the gaussian id is not written: pass 0 of the depth sort synthesises the identity payload, 8 B per gaussian less traffic)
     const float p[3] = {sc.means[3 * i], sc.means[3 * i + 1], sc.means[3 * i + 2]};
     const float *V = cam.V, *F = cam.F;
     // project_to_camera_space, rasterize.py:80-86
@@ -169,16 +169,18 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
         // that cannot touch a pixel here; they stay in the sort with an empty tile rect
         if (keep_ref_drawn && ref_drawn) {
             depth_key[i] = __float_as_uint(cm[2]);
-            rect[i] = make_ushort4(0, 0, 0, 0);
-            rect8[i] = 1u;  // packed {x0 = 1, y0 = 0, x1 - 1 = 0, y1 - 1 = 0}: zero width, i.e. no tiles
+            // only the form the binning will read is written: packed bytes ride through the depth sort as its second
+            // payload when the frame has at most 256 x 256 tiles, otherwise the rect is gathered by gaussian id
+            if (packed_rect) rect8[i] = 1u;  // packed {x0 = 1, y0 = 0, x1 - 1 = 0, y1 - 1 = 0}: zero width, i.e. no tiles
+            else rect[i] = make_ushort4(0, 0, 0, 0);
         } else {
             depth_key[i] = KEY_INVALID;
         }
         return;
     }
     depth_key[i] = __float_as_uint(cm[2]);  // z >= 0.2 > 0: IEEE bits are monotone in z (rasterize.py:424-425)
-    rect[i] = make_ushort4((unsigned short)tx0, (unsigned short)ty0, (unsigned short)tx1, (unsigned short)ty1);
-    rect8[i] = (uint32_t)(tx0 & 255) | ((uint32_t)(ty0 & 255) << 8) | ((uint32_t)((tx1 - 1) & 255) << 16) | ((uint32_t)((ty1 - 1) & 255) << 24);
+    if (packed_rect) rect8[i] = (uint32_t)(tx0 & 255) | ((uint32_t)(ty0 & 255) << 8) | ((uint32_t)((tx1 - 1) & 255) << 16) | ((uint32_t)((ty1 - 1) & 255) << 24);
+    else rect[i] = make_ushort4((unsigned short)tx0, (unsigned short)ty0, (unsigned short)tx1, (unsigned short)ty1);
     const float LOG2E = 1.4426950408889634f;
     GaussRec r;
     const float A = (-0.5f * sx) * LOG2E, B = (-sxy) * LOG2E, C = (-0.5f * sy) * LOG2E;
@@ -236,8 +238,8 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
 #define GSR_LAUNCH_PRE(DBG, H16, COL)                                                                                        \
     hipLaunchKernelGGL((preprocess_kernel<DBG, H16, COL>), dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat,       \
                        opts.no_footprint_cull, opts.tile_row_begin, opts.tile_row_step < 1 ? 1 : opts.tile_row_step,          \
-                       opts.draw_limit > 0 ? 1 : 0, ws.vis, ws.rec, ws.rect, ws.rect8[0], ws.key[0], ws.val[0], d,                     \
-                       reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words)
+                       opts.draw_limit > 0 ? 1 : 0, ws.vis, ws.rec, ws.rect, ws.rect8[0], ws.key[0], d,                     \
+                       reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, rect_fits_8bit(ws) ? 1 : 0)
     const bool h16 = scene.sh_dtype == 1;
     if (!with_color) GSR_LAUNCH_PRE(false, false, false);
     else if (dbg) { if (h16) GSR_LAUNCH_PRE(true, true, true); else GSR_LAUNCH_PRE(true, false, true); }

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
         const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
         const bool in = idx < n;
         key[r] = in ? keys_in[idx] : KEY_INVALID;
-        val[r] = in ? vals_in[idx] : 0u;
+        val[r] = in ? (vals_in ? vals_in[idx] : idx) : 0u;  // no value array: the payload is the element's index
         if (HAS_V2) val2[r] = in ? vals2_in[idx] : 0u;
     }
 #ifdef GSR_SORT_TRACE
@@ -234,8 +234,8 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
 
 template <int ITEMS, bool HAS_V2>
 static int sort_passes(uint32_t *const key[2], uint32_t *const val[2], uint32_t *const val2[2], const uint32_t *n_dev,
-                       int64_t n_bound, int passes, bool drop_invalid_first, uint32_t *n_out, const Workspace &ws,
-                       int *result_buf, hipStream_t s)
+                       int64_t n_bound, int passes, bool drop_invalid_first, bool index_values, uint32_t *n_out,
+                       const Workspace &ws, int *result_buf, hipStream_t s)
 {
     constexpr int TILE = SORT_THREADS * ITEMS;
     const int nblk = (int)((n_bound + TILE - 1) / TILE);
@@ -247,12 +247,13 @@ static int sort_passes(uint32_t *const key[2], uint32_t *const val[2], uint32_t 
         const int shift = 8 * p;
         const bool drop = drop_invalid_first && p == 0;
         const uint32_t *v2i = HAS_V2 ? val2[cur] : nullptr;
+        const uint32_t *vi = (index_values && p == 0) ? nullptr : val[cur];  // pass 0 can synthesise value = index
         uint32_t *v2o = HAS_V2 ? val2[cur ^ 1] : nullptr;
         if (drop) {
             hipLaunchKernelGGL((radix_hist_kernel<true, ITEMS>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], cnt_dev,
                                (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks);
             hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, s, ws.hist, ws.hist_blocks, nblk, dt);
-            hipLaunchKernelGGL((radix_scatter_kernel<true, ITEMS, HAS_V2>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], val[cur],
+            hipLaunchKernelGGL((radix_scatter_kernel<true, ITEMS, HAS_V2>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], vi,
                                v2i, key[cur ^ 1], val[cur ^ 1], v2o, cnt_dev, (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks,
                                dt, n_out);
             if (n_out) cnt_dev = n_out;  // later passes only see the survivors
@@ -260,7 +261,7 @@ static int sort_passes(uint32_t *const key[2], uint32_t *const val[2], uint32_t 
             hipLaunchKernelGGL((radix_hist_kernel<false, ITEMS>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], cnt_dev,
                                (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks);
             hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, s, ws.hist, ws.hist_blocks, nblk, dt);
-            hipLaunchKernelGGL((radix_scatter_kernel<false, ITEMS, HAS_V2>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], val[cur],
+            hipLaunchKernelGGL((radix_scatter_kernel<false, ITEMS, HAS_V2>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], vi,
                                v2i, key[cur ^ 1], val[cur ^ 1], v2o, cnt_dev, (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks,
                                dt, (uint32_t *)nullptr);
         }
@@ -272,14 +273,14 @@ static int sort_passes(uint32_t *const key[2], uint32_t *const val[2], uint32_t 
 }
 
 int launch_radix_sort(uint32_t *const key[2], uint32_t *const val[2], uint32_t *const val2[2], const uint32_t *n_dev,
-                      int64_t n_bound, int passes, bool drop_invalid_first, uint32_t *n_out, int items_per_thread,
-                      const Workspace &ws, int *result_buf, hipStream_t s)
+                      int64_t n_bound, int passes, bool drop_invalid_first, bool index_values, uint32_t *n_out,
+                      int items_per_thread, const Workspace &ws, int *result_buf, hipStream_t s)
 {
     *result_buf = 0;
     if (n_bound <= 0 || passes <= 0) return GSR_OK;
     if (items_per_thread != 16) { set_error("radix sort: unsupported items_per_thread %d", items_per_thread); return GSR_ERR_BAD_ARG; }
-    return val2 ? sort_passes<16, true>(key, val, val2, n_dev, n_bound, passes, drop_invalid_first, n_out, ws, result_buf, s)
-                : sort_passes<16, false>(key, val, val2, n_dev, n_bound, passes, drop_invalid_first, n_out, ws, result_buf, s);
+    return val2 ? sort_passes<16, true>(key, val, val2, n_dev, n_bound, passes, drop_invalid_first, index_values, n_out, ws, result_buf, s)
+                : sort_passes<16, false>(key, val, val2, n_dev, n_bound, passes, drop_invalid_first, index_values, n_out, ws, result_buf, s);
 }
 
 }  // namespace gsr
