@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--input_dir", default="", help="real data: MipNeRF-360 scene dir with sparse/0/{images,cameras}.bin")
     ap.add_argument("--trained_model_path", default="", help="real data: INRIA model dir (point_cloud/iteration_30000/point_cloud.ply)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-early-out-leg", action="store_true", help="skip the extra T<1e-4 measurement (profiling runs)")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     return ap.parse_args()
@@ -291,7 +292,7 @@ def main():
         # exact mode (no blend work skipped, reference semantics Q5); this line shows what north_star's "ballot early-out on
         # saturated alpha" buys inside its PSNR >= 50 dB tolerance
         eo_img = None
-        if args.early_out_T == 0.0:
+        if args.early_out_T == 0.0 and not args.no_early_out_leg:
             eo_T = 1e-4
             eo_opts = renderer.make_options(early_out_T=eo_T, blend_impl=args.blend_impl)
             eo_out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)

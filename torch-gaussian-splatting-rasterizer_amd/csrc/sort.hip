@@ -12,8 +12,8 @@
 // order or XCD placement):
 //   hist     one workgroup per tile of 256*ITEMS keys: 256-bin digit histogram -> hist[digit][tile]
 //   rowscan  one workgroup per digit: exclusive scan of its row in place, row total -> digit_tot[digit]
-//   scatter  one workgroup per tile: wave-ballot ranking -> tile reordered by digit in LDS -> digit runs
-//            written out contiguously (coalesced), position = digit base + scanned hist + rank in run
+//   scatter  one workgroup per tile: per-wave ranking through LDS peer masks -> tile reordered by digit in LDS -> digit
+//            runs written out contiguously (coalesced), position = digit base + scanned hist + rank in run
 // The element count lives in device memory (n_dev): grids are sized by the host-side bound and
 // surplus workgroups fall through.  4096-key tiles (16 keys per thread): 2048-key tiles measured slower, the
 // fixed per-workgroup costs (7 barriers, two 256-wide scans, 512 table loads) dominate small tiles.
@@ -46,7 +46,14 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
-    if (base < n) {
+    if (base + SORT_THREADS * ITEMS <= n) {  // full tile: unguarded loads, all in flight together
+        uint32_t k[ITEMS];
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) k[r] = keys[base + r * SORT_THREADS + threadIdx.x];
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r)
+            if (!DROP_INVALID || k[r] != KEY_INVALID) atomicAdd(&h[(k[r] >> shift) & 255u], 1u);
+    } else if (base < n) {
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const uint32_t idx = base + r * SORT_THREADS + threadIdx.x;
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t *__restrict
     if (threadIdx.x == 0) digit_tot[blockIdx.x] = carry;
 }
 
-template <bool DROP_INVALID, int ITEMS, bool HAS_V2>
+template <bool DROP_INVALID, int ITEMS, bool HAS_V2, bool INDEX_VALS>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint32_t *__restrict__ vals2_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t *__restrict__ vals2_out, const uint32_t *n_dev,
@@ -119,13 +126,23 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     // wave w owns items [w*64*ITEMS, (w+1)*64*ITEMS) of the tile, ITEMS rounds of 64 consecutive keys:
     // tile order == (wave, round, lane) order, which is what keeps the sort stable.
     uint32_t key[ITEMS], val[ITEMS], val2[HAS_V2 ? ITEMS : 1], rank[ITEMS];
+    if (base + TILE <= n) {  // full tile (all but the last workgroup): unguarded loads, all in flight together
 #pragma unroll
-    for (int r = 0; r < ITEMS; ++r) {
-        const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
-        const bool in = idx < n;
-        key[r] = in ? keys_in[idx] : KEY_INVALID;
-        val[r] = in ? (vals_in ? vals_in[idx] : idx) : 0u;  // no value array: the payload is the element's index
-        if (HAS_V2) val2[r] = in ? vals2_in[idx] : 0u;
+        for (int r = 0; r < ITEMS; ++r) {
+            const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
+            key[r] = keys_in[idx];
+            val[r] = INDEX_VALS ? idx : vals_in[idx];  // INDEX_VALS: the payload is the element's index, nothing to load
+            if (HAS_V2) val2[r] = vals2_in[idx];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
+            const bool in = idx < n;
+            key[r] = in ? keys_in[idx] : KEY_INVALID;
+            val[r] = INDEX_VALS ? idx : (in ? vals_in[idx] : 0u);
+            if (HAS_V2) val2[r] = in ? vals2_in[idx] : 0u;
+        }
     }
 #ifdef GSR_SORT_TRACE
     { uint32_t acc = 0;
@@ -134,6 +151,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
       asm volatile("" ::"v"(acc)); }  // wait for the loads
 #endif
     GSR_STAMP(1);
+    {
     // Ranking: for every key, how many EARLIER keys of this wave carry the same digit (earlier round, or same round and
     // lower lane) -- what keeps the sort stable.  The lanes of one round that share a digit find each other through LDS:
     // each ORs its lane bit into peer[digit], reads the mask back and clears it.  DS instructions of one wave execute in
@@ -182,6 +200,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
             const uint32_t p = (uint32_t)__shfl((int)prior[q], __ffsll((long long)m[q]) - 1, 64);  // from the group's lowest lane
             rank[r] = valid ? p + (uint32_t)__popcll(m[q] & lt_mask) : 0xFFFFFFFFu;
         }
+    }
     }
     __syncthreads();
     GSR_STAMP(2);
@@ -234,8 +253,8 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
 
 template <int ITEMS, bool HAS_V2>
 static int sort_passes(uint32_t *const key[2], uint32_t *const val[2], uint32_t *const val2[2], const uint32_t *n_dev,
-                       int64_t n_bound, int passes, bool drop_invalid_first, bool index_values, uint32_t *n_out,
-                       const Workspace &ws, int *result_buf, hipStream_t s)
+                       int64_t n_bound, int passes, bool drop_invalid_first, bool index_values,
+                       uint32_t *n_out, const Workspace &ws, int *result_buf, hipStream_t s)
 {
     constexpr int TILE = SORT_THREADS * ITEMS;
     const int nblk = (int)((n_bound + TILE - 1) / TILE);
@@ -247,24 +266,27 @@ static int sort_passes(uint32_t *const key[2], uint32_t *const val[2], uint32_t 
         const int shift = 8 * p;
         const bool drop = drop_invalid_first && p == 0;
         const uint32_t *v2i = HAS_V2 ? val2[cur] : nullptr;
-        const uint32_t *vi = (index_values && p == 0) ? nullptr : val[cur];  // pass 0 can synthesise value = index
         uint32_t *v2o = HAS_V2 ? val2[cur ^ 1] : nullptr;
+        const bool ident = index_values && p == 0;  // pass 0 can synthesise value = index instead of loading it
+#define GSR_HIST(DROP)                                                                                                             \
+    hipLaunchKernelGGL((radix_hist_kernel<DROP, ITEMS>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], cnt_dev, (uint32_t)n_bound, \
+                       shift, ws.hist, ws.hist_blocks)
+#define GSR_SCATTER(DROP, IDENT)                                                                                                   \
+    hipLaunchKernelGGL((radix_scatter_kernel<DROP, ITEMS, HAS_V2, IDENT>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], val[cur], \
+                       v2i, key[cur ^ 1], val[cur ^ 1], v2o, cnt_dev, (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks, dt,         \
+                       drop ? n_out : (uint32_t *)nullptr)
         if (drop) {
-            hipLaunchKernelGGL((radix_hist_kernel<true, ITEMS>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], cnt_dev,
-                               (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks);
+            GSR_HIST(true);
             hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, s, ws.hist, ws.hist_blocks, nblk, dt);
-            hipLaunchKernelGGL((radix_scatter_kernel<true, ITEMS, HAS_V2>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], vi,
-                               v2i, key[cur ^ 1], val[cur ^ 1], v2o, cnt_dev, (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks,
-                               dt, n_out);
+            if (ident) GSR_SCATTER(true, true); else GSR_SCATTER(true, false);
             if (n_out) cnt_dev = n_out;  // later passes only see the survivors
         } else {
-            hipLaunchKernelGGL((radix_hist_kernel<false, ITEMS>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], cnt_dev,
-                               (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks);
+            GSR_HIST(false);
             hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, s, ws.hist, ws.hist_blocks, nblk, dt);
-            hipLaunchKernelGGL((radix_scatter_kernel<false, ITEMS, HAS_V2>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], vi,
-                               v2i, key[cur ^ 1], val[cur ^ 1], v2o, cnt_dev, (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks,
-                               dt, (uint32_t *)nullptr);
+            if (ident) GSR_SCATTER(false, true); else GSR_SCATTER(false, false);
         }
+#undef GSR_SCATTER
+#undef GSR_HIST
         GSR_HIP(hipGetLastError());
         cur ^= 1;
     }
@@ -273,8 +295,8 @@ static int sort_passes(uint32_t *const key[2], uint32_t *const val[2], uint32_t 
 }
 
 int launch_radix_sort(uint32_t *const key[2], uint32_t *const val[2], uint32_t *const val2[2], const uint32_t *n_dev,
-                      int64_t n_bound, int passes, bool drop_invalid_first, bool index_values, uint32_t *n_out,
-                      int items_per_thread, const Workspace &ws, int *result_buf, hipStream_t s)
+                      int64_t n_bound, int passes, bool drop_invalid_first, bool index_values,
+                      uint32_t *n_out, int items_per_thread, const Workspace &ws, int *result_buf, hipStream_t s)
 {
     *result_buf = 0;
     if (n_bound <= 0 || passes <= 0) return GSR_OK;
