@@ -173,8 +173,10 @@ int gsr_render_batch(const GsrScene *scene, const GsrCamera *cams /* [host] */, 
                      int64_t max_pairs, void *workspace, size_t workspace_bytes, float *out_images, int64_t frame_stride,
                      void *stream);
 
-/* Copies the frame counters to host memory and waits for the stream.  Returns GSR_ERR_PAIR_OVERFLOW if the
- * frame overflowed max_pairs. */
+/* Totals the blend's per-workgroup counters (one small kernel on `stream`: wave_entries / fetched_entries describe the
+ * LAST gsr_blend of the frame, 0 if none ran), copies the frame counters to host memory and waits for the stream.
+ * Returns GSR_ERR_PAIR_OVERFLOW if the frame overflowed max_pairs.  `workspace` is const in the sense that no frame
+ * data changes; the two totals are written into its counter block. */
 int gsr_read_stats(const void *workspace, size_t workspace_bytes, GsrStats *out /* [host] */, void *stream);
 
 /* Stand-alone helpers behind the reference's helper functions (same maths as inside gsr_preprocess). */
