@@ -276,7 +276,7 @@ def main():
         result["roofline"] = {"kernel": "gsr::blend_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                               "algorithmic_bytes_per_launch": blend_bytes, "avg_kernel_ms": stage[2],
-                              "note": "blend is VALU-bound in exact mode (SURVEY.md §7 hard part 1): see valu_issue_frac; traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE from profiles/"}
+                              "note": "blend is bound on-chip in exact mode (VALU issue + LDS broadcast pipe 72 % busy, DESIGN.md §5; SURVEY.md §7 hard part 1): see valu_issue_frac; traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE from profiles/"}
         # honesty figure: the blend is VALU-bound.  64 pixel evaluations per evaluated (quadrant, entry);
         # rocprofv3 PMC (profiles/r1_pmc.json) counts 21.4 VALU wave-instructions per of them (17 in the inner loop + culling,
         # staging).  Peak issue = one fp32 VALU wave-instruction per 2 cycles per SIMD (tools/valu_microbench.hip), 1024 SIMDs,
