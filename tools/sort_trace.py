@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Phase timeline of the LAST radix scatter launch of a frame (tile sort, final pass).  Needs sort.hip built with
--DGSR_SORT_TRACE.  Phases: 0 start, 1 keys loaded, 2 ranked, 3 bases scanned, 4 reordered in LDS, 5 written out.
+"""Phase timeline of one radix scatter launch of the tile sort: the final pass (sort.hip built with -DGSR_SORT_TRACE) or
+pass 0, the one that drops culled pairs (-DGSR_SORT_TRACE -DGSR_SORT_TRACE_DROP=1, run with GSR_TRACE_PASS0=1).  Phases: 0 start, 1 keys loaded, 2 ranked, 3 bases scanned, 4 reordered in LDS, 5 written out.
 GPU analysis tool."""
 import argparse
 import ctypes as C
@@ -32,7 +32,7 @@ def main():
     rc = lib.gsr_debug_sort_trace(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.nbytes))
     assert rc == 0, rc
     st = buf.reshape(-1, 8)
-    nblk = (R.last_stats["n_pairs"] + 4095) // 4096
+    nblk = ((R.last_stats["n_pairs_bbox"] if os.environ.get("GSR_TRACE_PASS0") else R.last_stats["n_pairs"]) + 4095) // 4096
     st = st[:nblk].astype(np.int64)
     base = st[:, 0].min()
     t = (st[:, :6] - base) * 0.01

@@ -255,16 +255,16 @@ int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     int buf = 0;
-    // depth order: 4 x 8-bit passes over the 32 key bits; pass 0 drops culled gaussians and leaves V in ctrl
+    // depth order: 32 key bits = 4 x 8-bit passes; pass 0 drops culled gaussians and leaves V in ctrl
     const bool packed = rect_fits_8bit(ws);
-    rc = launch_radix_sort(ws.key, ws.val, packed ? ws.rect8 : nullptr, nullptr, n, 4, true, true, &ws.ctrl->n_visible,
+    rc = launch_radix_sort(ws.key, ws.val, packed ? ws.rect8 : nullptr, nullptr, n, 32, true, true, &ws.ctrl->n_visible,
                            DEPTH_SORT_ITEMS, ws, &buf, s);
     if (rc) return rc;
     rc = launch_binning(*cam, *opts, ws, buf, packed, s);
     if (rc) return rc;
     int pbuf = 0;
     // tile lists: stable sort by tile id; pass 0 drops the pairs the emit kernel culled and leaves E in ctrl
-    rc = launch_radix_sort(ws.pkey, ws.pval, nullptr, &ws.ctrl->n_slots, max_pairs, tile_sort_passes(ws.tiles_x * ws.tiles_y), true, false,
+    rc = launch_radix_sort(ws.pkey, ws.pval, nullptr, &ws.ctrl->n_slots, max_pairs, tile_key_bits(ws.tiles_x * ws.tiles_y), true, false,
                            &ws.ctrl->n_pairs, PAIR_SORT_ITEMS, ws, &pbuf, s);
     if (rc) return rc;
     return launch_tile_ranges(ws, pbuf, s);
@@ -277,7 +277,7 @@ int gsr_blend(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t m
     Workspace ws;
     int rc = check_frame(n, cam, opts, max_pairs, workspace, workspace_bytes, &ws);
     if (rc) return rc;
-    const int pbuf = tile_sort_passes(ws.tiles_x * ws.tiles_y) & 1;  // ping-pong parity of the tile sort
+    const int pbuf = ((tile_key_bits(ws.tiles_x * ws.tiles_y) + 7) / 8) & 1;  // ping-pong parity of the tile sort's passes
     return launch_blend(*cam, *opts, ws, max_pairs > 0 ? pbuf : 0, out_image, out_final_T, static_cast<hipStream_t>(stream));
 }
 

@@ -251,11 +251,11 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t *__rest
     }
 }
 
-int tile_sort_passes(int tiles)
+int tile_key_bits(int tiles)
 {
     int bits = 1;
     while ((1 << bits) < tiles) ++bits;
-    return (bits + 7) / 8;
+    return bits;
 }
 
 int launch_binning(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int sorted_buf, bool packed_rect,

@@ -99,7 +99,7 @@ int launch_rasterize_gaussian(int64_t g, const int64_t *bboxes, float *screen, c
 // On return *result_buf (0/1) tells which of key[]/val[] holds the sorted data.
 // val2 (may be nullptr): a second u32 payload moved along with val.  items_per_thread: 8 or 16.
 int launch_radix_sort(uint32_t *const key[2], uint32_t *const val[2], uint32_t *const val2[2], const uint32_t *n_dev,
-                      int64_t n_bound, int passes, bool drop_invalid_first, bool index_values,
+                      int64_t n_bound, int key_bits, bool drop_invalid_first, bool index_values,
                       uint32_t *n_out, int items_per_thread, const Workspace &ws, int *result_buf, hipStream_t s);
 
 int launch_binning(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int sorted_buf, bool packed_rect,
@@ -111,7 +111,7 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
 int launch_blend_stats(FrameCtrl *ctrl, size_t workspace_bytes, hipStream_t s);
 
 // which pair buffer holds the tile-sorted pairs, given the tile count (passes parity)
-int tile_sort_passes(int tiles);
+int tile_key_bits(int tiles);
 
 // ---- small device helpers -----------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)

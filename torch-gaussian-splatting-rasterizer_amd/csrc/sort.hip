@@ -1,4 +1,4 @@
-// sort.hip — stable LSD radix sort of (u32 key, u32 value[, u32 value2]) records, 8 bits per pass.
+// sort.hip — stable LSD radix sort of (u32 key, u32 value[, u32 value2]) records, up to 8 bits per pass (key bits split evenly over the passes).
 //
 // Used twice per frame (rasterize.py:424-425 is one torch.sort; tile lists have no reference counterpart):
 //   1. depth order:  keys = IEEE bits of z_cam of every gaussian (KEY_INVALID for culled ones, dropped
@@ -18,13 +18,17 @@
 // surplus workgroups fall through.  4096-key tiles (16 keys per thread): 2048-key tiles measured slower, the
 // fixed per-workgroup costs (7 barriers, two 256-wide scans, 512 table loads) dominate small tiles.
 // Roofline: HBM.  Per pass per element: 4 B (hist) + 8..12 B read + 8..12 B written.
+#include <algorithm>
 #include "gsr_internal.h"
 
 namespace gsr {
 
 #ifdef GSR_SORT_TRACE  // tools/sort_trace.py: per-workgroup phase stamps of the scatter kernel (100 MHz wall clock)
 __device__ uint32_t g_sort_trace[16384 * 8];
-#define GSR_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_sort_trace[blockIdx.x * 8 + (k)] = (uint32_t)wall_clock64(); } while (0)
+#ifndef GSR_SORT_TRACE_DROP
+#define GSR_SORT_TRACE_DROP 0
+#endif
+#define GSR_STAMP(k) do { if (DROP_INVALID == (GSR_SORT_TRACE_DROP != 0) && !HAS_V2 && threadIdx.x == 0 && blockIdx.x < 16384) g_sort_trace[blockIdx.x * 8 + (k)] = (uint32_t)wall_clock64(); } while (0)
 #else
 #define GSR_STAMP(k) do {} while (0)
 #endif
@@ -38,8 +42,8 @@ __device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t n
 
 template <bool DROP_INVALID, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t *__restrict__ keys, const uint32_t *n_dev,
-                                                                  uint32_t n_bound, int shift, uint32_t *__restrict__ hist,
-                                                                  int hist_blocks)
+                                                                  uint32_t n_bound, int shift, uint32_t mask,
+                                                                  uint32_t *__restrict__ hist, int hist_blocks)
 {
     __shared__ uint32_t h[256];
     const uint32_t n = load_count(n_dev, n_bound);
@@ -52,14 +56,14 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
         for (int r = 0; r < ITEMS; ++r) k[r] = keys[base + r * SORT_THREADS + threadIdx.x];
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r)
-            if (!DROP_INVALID || k[r] != KEY_INVALID) atomicAdd(&h[(k[r] >> shift) & 255u], 1u);
+            if (!DROP_INVALID || k[r] != KEY_INVALID) atomicAdd(&h[(k[r] >> shift) & mask], 1u);
     } else if (base < n) {
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const uint32_t idx = base + r * SORT_THREADS + threadIdx.x;
             if (idx < n) {
                 const uint32_t k = keys[idx];
-                if (!DROP_INVALID || k != KEY_INVALID) atomicAdd(&h[(k >> shift) & 255u], 1u);
+                if (!DROP_INVALID || k != KEY_INVALID) atomicAdd(&h[(k >> shift) & mask], 1u);
             }
         }
     }
@@ -96,8 +100,8 @@ template <bool DROP_INVALID, int ITEMS, bool HAS_V2, bool INDEX_VALS>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint32_t *__restrict__ vals2_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t *__restrict__ vals2_out, const uint32_t *n_dev,
-    uint32_t n_bound, int shift, const uint32_t *__restrict__ hist, int hist_blocks, const uint32_t *__restrict__ digit_tot,
-    uint32_t *n_out)
+    uint32_t n_bound, int shift, uint32_t mask, const uint32_t *__restrict__ hist, int hist_blocks,
+    const uint32_t *__restrict__ digit_tot, uint32_t *n_out)
 {
     constexpr int TILE = SORT_THREADS * ITEMS;
     __shared__ uint32_t wave_cnt[4][256];   // per-wave digit counts, then per-wave exclusive bases
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
             const int r = r0 + q;
             const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
             const bool valid = (idx < n) && (!DROP_INVALID || key[r] != KEY_INVALID);
-            const uint32_t d = (key[r] >> shift) & 255u;
+            const uint32_t d = (key[r] >> shift) & mask;
             m[q] = my_bit;
             if (valid) {
                 __hip_atomic_fetch_or(&pm[d], my_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
             const int r = r0 + q;
             const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
             const bool valid = (idx < n) && (!DROP_INVALID || key[r] != KEY_INVALID);
-            const uint32_t d = (key[r] >> shift) & 255u;
+            const uint32_t d = (key[r] >> shift) & mask;
             prior[q] = 0;
             if (valid && (m[q] & lt_mask) == 0)
                 prior[q] = __hip_atomic_fetch_add(&wc[d], (uint32_t)__popcll(m[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         if (rank[r] != 0xFFFFFFFFu) {
-            const uint32_t d = (key[r] >> shift) & 255u;
+            const uint32_t d = (key[r] >> shift) & mask;
             const uint32_t pos = tile_start[d] + wave_cnt[wave][d] + rank[r];
             skey[pos] = key[r];
             sval[pos] = val[r];
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const uint32_t nvalid = s_valid;
     for (uint32_t i = tid; i < nvalid; i += SORT_THREADS) {
         const uint32_t k = skey[i];
-        const uint32_t d = (k >> shift) & 255u;
+        const uint32_t d = (k >> shift) & mask;
         const uint32_t gpos = digit_base[d] + (i - tile_start[d]);
         keys_out[gpos] = k;
         vals_out[gpos] = sval[i];
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
 
 template <int ITEMS, bool HAS_V2>
 static int sort_passes(uint32_t *const key[2], uint32_t *const val[2], uint32_t *const val2[2], const uint32_t *n_dev,
-                       int64_t n_bound, int passes, bool drop_invalid_first, bool index_values,
+                       int64_t n_bound, int key_bits, bool drop_invalid_first, bool index_values,
                        uint32_t *n_out, const Workspace &ws, int *result_buf, hipStream_t s)
 {
     constexpr int TILE = SORT_THREADS * ITEMS;
@@ -262,18 +266,23 @@ static int sort_passes(uint32_t *const key[2], uint32_t *const val[2], uint32_t 
     int cur = 0;
     const uint32_t *cnt_dev = n_dev;
     uint32_t *dt = ws.ctrl->digit_tot;
+    // digits: as few passes as 8-bit digits allow, the key bits split evenly over them (13 tile-id bits -> 7 + 6, not 8 + 5:
+    // fewer digit values per pass mean longer runs per workgroup, i.e. fuller 128-B lines in the scattered writes)
+    const int passes = (key_bits + 7) / 8;
+    const int bits_pp = (key_bits + passes - 1) / passes;
     for (int p = 0; p < passes; ++p) {
-        const int shift = 8 * p;
+        const int shift = bits_pp * p;
+        const uint32_t mask = (1u << std::min(bits_pp, key_bits - shift)) - 1u;
         const bool drop = drop_invalid_first && p == 0;
         const uint32_t *v2i = HAS_V2 ? val2[cur] : nullptr;
         uint32_t *v2o = HAS_V2 ? val2[cur ^ 1] : nullptr;
         const bool ident = index_values && p == 0;  // pass 0 can synthesise value = index instead of loading it
 #define GSR_HIST(DROP)                                                                                                             \
     hipLaunchKernelGGL((radix_hist_kernel<DROP, ITEMS>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], cnt_dev, (uint32_t)n_bound, \
-                       shift, ws.hist, ws.hist_blocks)
+                       shift, mask, ws.hist, ws.hist_blocks)
 #define GSR_SCATTER(DROP, IDENT)                                                                                                   \
     hipLaunchKernelGGL((radix_scatter_kernel<DROP, ITEMS, HAS_V2, IDENT>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], val[cur], \
-                       v2i, key[cur ^ 1], val[cur ^ 1], v2o, cnt_dev, (uint32_t)n_bound, shift, ws.hist, ws.hist_blocks, dt,         \
+                       v2i, key[cur ^ 1], val[cur ^ 1], v2o, cnt_dev, (uint32_t)n_bound, shift, mask, ws.hist, ws.hist_blocks, dt,         \
                        drop ? n_out : (uint32_t *)nullptr)
         if (drop) {
             GSR_HIST(true);
@@ -295,14 +304,14 @@ static int sort_passes(uint32_t *const key[2], uint32_t *const val[2], uint32_t 
 }
 
 int launch_radix_sort(uint32_t *const key[2], uint32_t *const val[2], uint32_t *const val2[2], const uint32_t *n_dev,
-                      int64_t n_bound, int passes, bool drop_invalid_first, bool index_values,
+                      int64_t n_bound, int key_bits, bool drop_invalid_first, bool index_values,
                       uint32_t *n_out, int items_per_thread, const Workspace &ws, int *result_buf, hipStream_t s)
 {
     *result_buf = 0;
-    if (n_bound <= 0 || passes <= 0) return GSR_OK;
+    if (n_bound <= 0 || key_bits <= 0) return GSR_OK;
     if (items_per_thread != 16) { set_error("radix sort: unsupported items_per_thread %d", items_per_thread); return GSR_ERR_BAD_ARG; }
-    return val2 ? sort_passes<16, true>(key, val, val2, n_dev, n_bound, passes, drop_invalid_first, index_values, n_out, ws, result_buf, s)
-                : sort_passes<16, false>(key, val, val2, n_dev, n_bound, passes, drop_invalid_first, index_values, n_out, ws, result_buf, s);
+    return val2 ? sort_passes<16, true>(key, val, val2, n_dev, n_bound, key_bits, drop_invalid_first, index_values, n_out, ws, result_buf, s)
+                : sort_passes<16, false>(key, val, val2, n_dev, n_bound, key_bits, drop_invalid_first, index_values, n_out, ws, result_buf, s);
 }
 
 }  // namespace gsr
