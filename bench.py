@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--input_dir", default="", help="real data: MipNeRF-360 scene dir with sparse/0/{images,cameras}.bin")
     ap.add_argument("--trained_model_path", default="", help="real data: INRIA model dir (point_cloud/iteration_30000/point_cloud.ply)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bf16-output", action="store_true", help="store the frame as bfloat16 (configs[2]); accumulation stays fp32")
     ap.add_argument("--no-early-out-leg", action="store_true", help="skip the extra T<1e-4 measurement (profiling runs)")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
@@ -153,11 +154,12 @@ def main():
     cam = cams[0]
     ncam = len(cams)
     plan = gdist.TileRowPlan(H, W, world)
-    fg = gdist.FrameGather(plan, rank, dev)
+    out_dtype = torch.bfloat16 if args.bf16_output else torch.float32
+    fg = gdist.FrameGather(plan, rank, dev, dtype=out_dtype)
     R = renderer.Rasterizer(scene, overlap=args.overlap)
     state1 = {"i": 0}
     if world == 1:  # no sharding: blend straight into the frame
-        opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl)
+        opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl, output_bf16=args.bf16_output)
         strip_view = fg.frame
 
         def step():
@@ -165,7 +167,8 @@ def main():
             state1["i"] += 1
             return R.enqueue(c, opts, out=strip_view)
     else:
-        opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl, **plan.shard_options(rank))
+        opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl, output_bf16=args.bf16_output,
+                                     **plan.shard_options(rank))
         strip_view = fg.own_view(0)
         state = {"i": 0, "pending": None}
 
@@ -227,6 +230,7 @@ def main():
                        "camera": args.camera if ncam == 1 else f"cycling over {ncam} cameras",
                        "sharding": f"tile rows interleaved over {world} GPU(s), RCCL gather to rank 0" if world > 1 else "none",
                        "reference_compat": True, "early_out_T": args.early_out_T, "sh_storage": "f16" if sh_half else "f32",
+                       "frame_storage": "bf16 (fp32 accumulation)" if args.bf16_output else "f32",
                        "blend_impl": "mfma" if args.blend_impl == 2 else "valu",
                        "streams": "2 (SH colour pass under the sorts)" if args.overlap else 1},
             "stats_rank0_shard": shard_stats,
@@ -328,7 +332,7 @@ def main():
                 screen, _, drawn = orc.composite(order, pre, W, H, threads=threads)
                 t_comp = time.perf_counter() - t1
                 oracle_img = screen.transpose(1, 0, 2)
-                img = frame.cpu().numpy()
+                img = frame.float().cpu().numpy()
                 mse = float(np.mean((img.astype(np.float64) - oracle_img) ** 2))
                 result["psnr_vs_oracle_db"] = None if mse == 0 else 10 * np.log10(1.0 / mse)
                 result["max_abs_vs_oracle"] = float(np.abs(img - oracle_img).max())

@@ -90,6 +90,10 @@ typedef struct GsrOptions {
     int32_t draw_limit;       /* 0 (default): blend everything.  k > 0: blend only the first k gaussians of the reference's
                                  draw order (depth order restricted to those its skip guard rasterize.py:441 lets through) —
                                  the progressive frames of --generate_video (rasterize.py:448-450). */
+    int32_t output_dtype;     /* 0 (default): the frame is float32.  1: the frame is stored as bfloat16 (round to nearest even),
+                                 6 B per pixel (BASELINE configs[2]); T and the colour sums are ALWAYS accumulated in fp32
+                                 registers — bf16 accumulators measure 41 dB, below the 50 dB bar.
+                                 out_final_T stays float32. */
 } GsrOptions;
 
 /* Counters of one frame (device -> host with gsr_read_stats). */
@@ -159,18 +163,19 @@ int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_
  * n and max_pairs must be the values given to the earlier stages (the library keeps no state; they fix the
  * workspace layout). */
 int gsr_blend(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs, void *workspace,
-              size_t workspace_bytes, float *out_image, float *out_final_T, void *stream);
+              size_t workspace_bytes, void *out_image /* float32 or bfloat16, opts->output_dtype */, float *out_final_T,
+              void *stream);
 
 /* Stages 1-3 back to back: the whole render call of rasterize.py:354-446. */
 int gsr_render_forward(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,
-                       void *workspace, size_t workspace_bytes, float *out_image, float *out_final_T, void *stream);
+                       void *workspace, size_t workspace_bytes, void *out_image, float *out_final_T, void *stream);
 
 /* Several views of ONE resident scene, enqueued back to back on the stream with one workspace (the reference renders
  * one view per process, rasterize.py:315-329).  cams[n_cams] [host] must share width/height; frame i goes to
- * out_images + i * frame_stride (floats).  Counters afterwards describe the LAST view; an overflow in any view is
+ * out_images + i * frame_stride (in elements of the output dtype).  Counters afterwards describe the LAST view; an overflow in any view is
  * sticky in them. */
 int gsr_render_batch(const GsrScene *scene, const GsrCamera *cams /* [host] */, int32_t n_cams, const GsrOptions *opts,
-                     int64_t max_pairs, void *workspace, size_t workspace_bytes, float *out_images, int64_t frame_stride,
+                     int64_t max_pairs, void *workspace, size_t workspace_bytes, void *out_images, int64_t frame_stride,
                      void *stream);
 
 /* Totals the blend's per-workgroup counters (one small kernel on `stream`: wave_entries / fetched_entries describe the

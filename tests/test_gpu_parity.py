@@ -412,3 +412,25 @@ def test_blend_counters_describe_the_last_blend(G):
         R.render(cam, G.renderer.make_options(tile_row_begin=r, tile_row_step=3, output_layout=2))
         tot += R.last_stats["fetched_entries"]
     assert first["fetched_entries"] <= tot <= 1.1 * first["fetched_entries"]
+
+
+def test_bf16_frame_storage_is_the_rounded_fp32_frame(G):
+    """GsrOptions.output_dtype = 1 (BASELINE configs[2]): accumulation stays fp32, only the store is bfloat16 —
+    bit for bit torch's round-to-nearest-even of the fp32 frame, in every layout and through the batch entry."""
+    cols, cam, ocam = _medium(G, n=60_000)
+    packed = G.utils.pack_gaussians(cols)
+    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(packed))
+    mk = G.renderer.make_options
+    ref = R.render(cam)
+    got = R.render(cam, mk(output_bf16=True))
+    assert got.dtype == torch.bfloat16 and torch.equal(got, ref.to(torch.bfloat16))
+    oimg, _ = G.orc.render(packed, ocam)
+    assert psnr(got.float().cpu().numpy(), oimg) >= 55.0     # 8 mantissa bits of storage; the bar is 50 dB
+    for extra in (dict(output_layout=1), dict(tile_row_begin=1, tile_row_step=3, output_layout=2), dict(blend_impl=2)):
+        a = R.render(cam, mk(**extra))
+        b = R.render(cam, mk(output_bf16=True, **extra))
+        assert torch.equal(b, a.to(torch.bfloat16))
+    batch = R.render_batch([cam, cam], mk(output_bf16=True))
+    assert batch.dtype == torch.bfloat16 and torch.equal(batch[0], got) and torch.equal(batch[1], got)
+    with pytest.raises(ValueError):
+        R.render(cam, mk(output_bf16=True), out=torch.empty_like(ref))

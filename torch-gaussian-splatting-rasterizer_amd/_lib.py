@@ -72,6 +72,7 @@ class GsrOptions(C.Structure):
         ("no_footprint_cull", C.c_int32),
         ("blend_impl", C.c_int32),
         ("draw_limit", C.c_int32),
+        ("output_dtype", C.c_int32),
     ]
 
 

@@ -78,6 +78,7 @@ static int check_frame(int64_t n, const GsrCamera *cam, const GsrOptions *opts, 
         set_error("bad tile-row shard %d/%d", opts->tile_row_begin, opts->tile_row_step); return GSR_ERR_BAD_ARG;
     }
     if (opts->draw_limit < 0) { set_error("bad draw_limit %d", opts->draw_limit); return GSR_ERR_BAD_ARG; }
+    if (opts->output_dtype != 0 && opts->output_dtype != 1) { set_error("bad output_dtype %d", opts->output_dtype); return GSR_ERR_BAD_ARG; }
     if (opts->blend_impl < 0 || opts->blend_impl > 2) { set_error("bad blend_impl %d", opts->blend_impl); return GSR_ERR_BAD_ARG; }
     if (opts->output_layout < 0 || opts->output_layout > 2) { set_error("bad output_layout %d", opts->output_layout); return GSR_ERR_BAD_ARG; }
     if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) { set_error("workspace must be 256-byte aligned"); return GSR_ERR_BAD_ARG; }
@@ -271,7 +272,7 @@ int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_
 }
 
 int gsr_blend(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs, void *workspace,
-              size_t workspace_bytes, float *out_image, float *out_final_T, void *stream)
+              size_t workspace_bytes, void *out_image, float *out_final_T, void *stream)
 {
     if (!out_image) { set_error("null output image"); return GSR_ERR_BAD_ARG; }
     Workspace ws;
@@ -282,17 +283,17 @@ int gsr_blend(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t m
 }
 
 static int render_forward_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,
-                               void *workspace, size_t workspace_bytes, float *out_image, float *out_final_T, void *stream,
+                               void *workspace, size_t workspace_bytes, void *out_image, float *out_final_T, void *stream,
                                bool keep_batch_words);
 
 int gsr_render_forward(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,
-                       void *workspace, size_t workspace_bytes, float *out_image, float *out_final_T, void *stream)
+                       void *workspace, size_t workspace_bytes, void *out_image, float *out_final_T, void *stream)
 {
     return render_forward_impl(scene, cam, opts, max_pairs, workspace, workspace_bytes, out_image, out_final_T, stream, false);
 }
 
 static int render_forward_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,
-                               void *workspace, size_t workspace_bytes, float *out_image, float *out_final_T, void *stream,
+                               void *workspace, size_t workspace_bytes, void *out_image, float *out_final_T, void *stream,
                                bool keep_batch_words)
 {
     int rc = check_scene(scene);
@@ -309,9 +310,9 @@ static int render_forward_impl(const GsrScene *scene, const GsrCamera *cam, cons
 }
 
 int gsr_render_batch(const GsrScene *scene, const GsrCamera *cams, int32_t n_cams, const GsrOptions *opts, int64_t max_pairs,
-                     void *workspace, size_t workspace_bytes, float *out_images, int64_t frame_stride, void *stream)
+                     void *workspace, size_t workspace_bytes, void *out_images, int64_t frame_stride, void *stream)
 {
-    if (!cams || n_cams < 0 || !out_images) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
+    if (!cams || n_cams < 0 || !out_images || !opts) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
     for (int32_t i = 0; i < n_cams; ++i) {
         if (cams[i].width != cams[0].width || cams[i].height != cams[0].height) { set_error("views of a batch must share one frame size"); return GSR_ERR_BAD_ARG; }
         if (frame_stride < (int64_t)cams[i].width * cams[i].height * 3) { set_error("frame_stride smaller than a frame"); return GSR_ERR_BAD_ARG; }
@@ -319,7 +320,8 @@ int gsr_render_batch(const GsrScene *scene, const GsrCamera *cams, int32_t n_cam
     for (int32_t i = 0; i < n_cams; ++i) {
         // view 0 clears the whole control block, later views keep the batch-sticky overflow words
         int rc = render_forward_impl(scene, &cams[i], opts, max_pairs, workspace, workspace_bytes,
-                                     out_images + (size_t)i * frame_stride, nullptr, stream, i > 0);
+                                     static_cast<char *>(out_images) + (size_t)i * frame_stride * (opts->output_dtype == 1 ? 2 : 4), nullptr, stream,
+                                     i > 0);
         if (rc) return rc;
     }
     return GSR_OK;

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
         if (a.layout == 0) o = ((size_t)py * a.W + px) * 3;                                           // image [H,W,3]
         else if (a.layout == 1) o = ((size_t)px * a.H + py) * 3;                                      // screen [W,H,3]
         else o = ((size_t)(((ty - a.row_begin) / a.row_step) * 16 + (py - ty * 16)) * a.W + px) * 3;  // strip
-        a.out[o] = r; a.out[o + 1] = g; a.out[o + 2] = b;
+        store_rgb(a, o, r, g, b);
         if (a.out_T) {
             const size_t ot = a.layout == 1 ? (size_t)px * a.H + py
                             : a.layout == 0 ? (size_t)py * a.W + px
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
     }
 }
 
-int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int pair_buf, float *out_image,
+int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int pair_buf, void *out_image,
                  float *out_T, hipStream_t s)
 {
     BlendArgs a;
@@ -213,6 +213,7 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     a.row_begin = opts.tile_row_begin;
     a.rows = a.row_begin < ws.tiles_y ? (ws.tiles_y - a.row_begin + a.row_step - 1) / a.row_step : 0;
     a.layout = opts.output_layout;
+    a.out_bf16 = opts.output_dtype == 1;
     a.early_T = opts.early_out_T;
     if (a.rows <= 0 || a.tiles_x <= 0) return GSR_OK;
     const int rows_per_xcd = (a.rows + 7) / 8;

@@ -8,7 +8,7 @@ struct BlendArgs {
     const uint2 *ranges;
     const uint32_t *pval;
     const GaussRec *rec;
-    float *out;
+    void *out;            // float32, or bfloat16 when out_bf16
     float *out_T;
     uint32_t *stats;      // [launch slots][BLEND_STAT_WORDS]
     const int *order;     // tile launch order (tile_order_kernel), -1 = empty slot
@@ -17,8 +17,25 @@ struct BlendArgs {
     int tiles_x;
     int row_begin, row_step, rows;  // tile rows of this shard: row_begin + k*row_step, k in [0, rows)
     int layout;
+    int out_bf16;
     float early_T;
 };
+
+// One pixel's colour into the frame.  bfloat16 = the upper half of the float, rounded to nearest even (values are finite).
+__device__ __forceinline__ void store_rgb(const BlendArgs &a, size_t o, float r, float g, float b)
+{
+    if (a.out_bf16) {
+        auto bf = [](float x) {
+            const uint32_t u = __float_as_uint(x);
+            return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+        };
+        unsigned short *p = static_cast<unsigned short *>(a.out) + o;
+        p[0] = bf(r); p[1] = bf(g); p[2] = bf(b);
+    } else {
+        float *p = static_cast<float *>(a.out) + o;
+        p[0] = r; p[1] = g; p[2] = b;
+    }
+}
 
 int launch_blend_mfma(const BlendArgs &a, unsigned grid, hipStream_t s);
 

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, 4) void blend_mfma_kernel(BlendArgs a)
         if (a.layout == 0) o = ((size_t)py * a.W + px) * 3;
         else if (a.layout == 1) o = ((size_t)px * a.H + py) * 3;
         else o = ((size_t)(((ty - a.row_begin) / a.row_step) * 16 + (py - ty * 16)) * a.W + px) * 3;
-        a.out[o] = r; a.out[o + 1] = g; a.out[o + 2] = b;
+        store_rgb(a, o, r, g, b);
         if (a.out_T) {
             const size_t ot = a.layout == 1 ? (size_t)px * a.H + py
                             : a.layout == 0 ? (size_t)py * a.W + px

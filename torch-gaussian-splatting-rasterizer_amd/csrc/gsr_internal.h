@@ -106,7 +106,7 @@ int launch_binning(const GsrCamera &cam, const GsrOptions &opts, const Workspace
                    hipStream_t s);
 inline bool rect_fits_8bit(const Workspace &ws) { return ws.tiles_x <= 256 && ws.tiles_y <= 256; }
 int launch_tile_ranges(const Workspace &ws, int pair_buf, hipStream_t s);
-int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int pair_buf, float *out_image,
+int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int pair_buf, void *out_image,
                  float *out_T, hipStream_t s);
 int launch_blend_stats(FrameCtrl *ctrl, size_t workspace_bytes, hipStream_t s);
 

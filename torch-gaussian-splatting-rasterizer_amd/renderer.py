@@ -82,7 +82,8 @@ def make_camera(qvec, tvec, fx_full: float, fy_full: float, cam_width: int, cam_
 
 
 def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_row_begin: int = 0, tile_row_step: int = 1,
-                 output_layout: int = 0, no_footprint_cull: bool = False, blend_impl: int = 0, draw_limit: int = 0) -> GsrOptions:
+                 output_layout: int = 0, no_footprint_cull: bool = False, blend_impl: int = 0, draw_limit: int = 0,
+                 output_bf16: bool = False) -> GsrOptions:
     o = _lib.default_options()
     o.reference_compat = 1 if reference_compat else 0
     o.early_out_T = float(early_out_T)
@@ -92,6 +93,7 @@ def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_r
     o.no_footprint_cull = 1 if no_footprint_cull else 0
     o.blend_impl = int(blend_impl)
     o.draw_limit = int(draw_limit)
+    o.output_dtype = 1 if output_bf16 else 0  # frame stored as bfloat16; accumulation stays fp32
     return o
 
 
@@ -143,12 +145,13 @@ class Rasterizer:
         opts = opts or make_options()
         ws = self._workspace(cam.width, cam.height)
         shape, _ = self._out_shape(cam, opts)
+        dtype = torch.bfloat16 if opts.output_dtype == 1 else torch.float32
         if out is None:
             # strips may include rows below the frame's last pixel row: keep them defined
-            out = torch.zeros(shape, dtype=torch.float32, device=self.scene.device) if opts.output_layout == 2 else \
-                torch.empty(shape, dtype=torch.float32, device=self.scene.device)
-        elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or not out.is_cuda:
-            raise ValueError(f"out must be a contiguous float32 CUDA tensor of shape {shape}")
+            out = torch.zeros(shape, dtype=dtype, device=self.scene.device) if opts.output_layout == 2 else \
+                torch.empty(shape, dtype=dtype, device=self.scene.device)
+        elif tuple(out.shape) != shape or out.dtype != dtype or not out.is_contiguous() or not out.is_cuda:
+            raise ValueError(f"out must be a contiguous {dtype} CUDA tensor of shape {shape}")
         if out.numel() == 0:  # a shard that owns no tile row (more ranks than tile rows): nothing to render
             return out
         sc = self.scene.c_struct()
@@ -211,8 +214,11 @@ class Rasterizer:
         cams = list(cams)
         arr = (GsrCamera * len(cams))(*cams)
         W, H = cams[0].width, cams[0].height
+        dtype = torch.bfloat16 if opts.output_dtype == 1 else torch.float32
         if out is None:
-            out = torch.empty((len(cams), H, W, 3), dtype=torch.float32, device=self.scene.device)
+            out = torch.empty((len(cams), H, W, 3), dtype=dtype, device=self.scene.device)
+        elif tuple(out.shape) != (len(cams), H, W, 3) or out.dtype != dtype or not out.is_contiguous() or not out.is_cuda:
+            raise ValueError(f"out must be a contiguous {dtype} CUDA tensor of shape {(len(cams), H, W, 3)}")
         sc = self.scene.c_struct()
         while True:
             ws = self._workspace(W, H)
