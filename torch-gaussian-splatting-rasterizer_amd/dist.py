@@ -82,9 +82,19 @@ class FrameGather:
     def __init__(self, plan: TileRowPlan, rank: int, device, dtype=torch.float32, group=None, buffers: int = 2):
         self.plan, self.rank, self.group = plan, rank, group
         self.strips = [torch.zeros(plan.padded_shape(), dtype=dtype, device=device) for _ in range(buffers)]
-        self.recvs = ([[torch.zeros(plan.padded_shape(), dtype=dtype, device=device) for _ in range(plan.world)]
-                       for _ in range(buffers)] if rank == 0 and plan.world > 1 else None)
-        self.frame = torch.zeros((plan.height, plan.width, 3), dtype=dtype, device=device) if rank == 0 else None
+        self.recvs = self._recv_all = self._row_src = None
+        self.frame = None
+        if rank == 0:
+            # the frame lives in a buffer padded to whole tile rows; `frame` is its first H pixel rows (contiguous)
+            self._frame_padded = torch.zeros((plan.tiles_y * TILE, plan.width, 3), dtype=dtype, device=device)
+            self.frame = self._frame_padded[: plan.height]
+            if plan.world > 1:
+                # one receive buffer per wire buffer, the gather list are views into it, so that de-interleaving the
+                # G strips is ONE index_select (one kernel, one Python call per frame on the root) instead of G copies
+                self._recv_all = [torch.zeros((plan.world,) + plan.padded_shape(), dtype=dtype, device=device) for _ in range(buffers)]
+                self.recvs = [[ra[r] for r in range(plan.world)] for ra in self._recv_all]
+                t = torch.arange(plan.tiles_y)
+                self._row_src = ((t % plan.world) * plan.max_rows + t // plan.world).to(device)  # frame tile row -> wire row
 
     @property
     def strip(self) -> torch.Tensor:
@@ -120,10 +130,15 @@ class FrameGather:
             work.wait()
         if self.rank != 0:
             return None
+        if self.plan.world == 1:
+            return self.plan.assemble([self.strips[buf]], self.frame)
         if host is not None:
             for dst, src in zip(self.recvs[buf], host):
                 dst.copy_(src)
-        return self.plan.assemble([self.strips[buf]] if self.plan.world == 1 else self.recvs[buf], self.frame)
+        row = TILE * self.plan.width * 3
+        torch.index_select(self._recv_all[buf].view(self.plan.world * self.plan.max_rows, row), 0, self._row_src,
+                           out=self._frame_padded.view(self.plan.tiles_y, row))
+        return self.frame
 
     def gather(self, buf: int = 0) -> Optional[torch.Tensor]:
         """Blocking form: every rank calls it after its strip is complete.  Rank 0 gets the frame."""
