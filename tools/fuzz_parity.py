@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Randomised parity campaign on the GPU: random scenes / frame sizes / cameras / options, HIP path (through the C ABI)
+against the C oracle, plus the bit-identity properties (sharding, culling off, bf16 store, repeat).  Not part of the test
+suite (open-ended run time); run it on the GPU box after touching a kernel:  python tools/fuzz_parity.py --seconds 120
+Checker only: imports oracle/.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-n", type=int, default=60000)
+    a = ap.parse_args()
+
+    import gsr_amd  # noqa: F401
+    from conftest import psnr
+    from gsr_amd import renderer, synthetic, utils
+    from oracle import cpu_oracle as orc
+
+    def close(x, ref):
+        """conftest.assert_frames_close for frames of any size: `alpha > 1/255` is a step function, so a pixel sitting on the
+        threshold may flip (by at most MIN_ALPHA * T * c < 4.5e-3, in colour and in T); on a tiny frame one flip already
+        exceeds a relative budget, so at least 3 flipped pixels are always allowed."""
+        d = np.abs(np.asarray(x, np.float64) - np.asarray(ref, np.float64))
+        assert d.max() <= 4.5e-3, f"max {d.max()}"
+        px = d.reshape(d.shape[0] * d.shape[1], -1).max(1)
+        assert (px > 1e-5).sum() <= max(3, 1e-4 * px.size), f"{(px > 1e-5).sum()} of {px.size} pixels off"
+        if d.size >= 300_000:
+            assert psnr(x, ref) >= 100.0, f"psnr {psnr(x, ref)}"
+
+    rng = np.random.default_rng(a.seed)
+    t_end = time.time() + a.seconds
+    cases = fails = 0
+    mk = renderer.make_options
+    while time.time() < t_end:
+        n = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, int(rng.integers(1, a.max_n))]))
+        W = int(rng.choice([1, 15, 16, 17, 31, 33, 160, 333, 640, int(rng.integers(1, 1300))]))
+        H = int(rng.choice([1, 15, 16, 17, 96, 197, 360, int(rng.integers(1, 800))]))
+        gen = synthetic.mip360_like if rng.random() < 0.7 else synthetic.uniform_box
+        cols = gen(n, int(rng.integers(0, 1 << 30)))
+        shift = float(rng.choice([0.0, 1.0, 2.0, 3.5]))
+        for i in range(3):
+            cols[f"scale_{i}"] = (cols[f"scale_{i}"] + np.float32(shift)).astype(np.float32)
+        if rng.random() < 0.2:  # stacks of exactly equal depth
+            k = int(rng.integers(1, 50))
+            for c in "xyz":
+                cols[c] = np.ascontiguousarray(cols[c][np.arange(n) % k])
+        if rng.random() < 0.2:
+            cols["opacity"] = np.full_like(cols["opacity"], float(rng.choice([-8.0, 6.0, 12.0])))
+        if gen is synthetic.uniform_box:
+            pose = synthetic.box_camera()
+        else:
+            th = rng.uniform(0, 2 * np.pi)
+            rad = float(rng.choice([0.5, 2.0, 4.0, 30.0]))
+            pose = synthetic.look_at_pose((rad * np.cos(th), rad * np.sin(th), rng.uniform(-1, 2)), (0, 0, 0), 1, "c.png")
+        fx = synthetic.pinhole_focal(max(W, 2), float(rng.choice([30.0, 60.0, 100.0])))
+        sf = int(rng.choice([1, 2, 4]))
+        args = (pose.qvec, pose.tvec, sf * fx, sf * fx, sf * W, sf * H, W, H)
+        cam, ocam = renderer.make_camera(*args), orc.camera(*args)
+        degree = int(rng.choice([3, 3, 3, 0, 1, 2]))
+        packed = utils.pack_gaussians(cols)
+        desc = f"n={n} {W}x{H} gen={gen.__name__} shift={shift} deg={degree} sf={sf}"
+        try:
+            scene = renderer.GaussianScene.from_packed(packed, sh_degree=degree) if degree != 3 else renderer.GaussianScene.from_packed(packed)
+            R = renderer.Rasterizer(scene, max_pairs=int(rng.choice([0, 1000])) or None)
+            img, T = R.render(cam, return_T=True)
+            oimg, oT, _ = orc.render(packed, ocam, sh_degree=degree, want_T=True)
+            close(img.cpu().numpy(), oimg)
+            close(T.cpu().numpy()[..., None], oT[..., None])
+            assert torch.equal(R.render(cam), img), "not reproducible"
+            assert torch.equal(R.render(cam, mk(no_footprint_cull=True)), img), "culling changes bits"
+            assert torch.equal(R.render(cam, mk(output_bf16=True)), img.to(torch.bfloat16)), "bf16 store"
+            step = int(rng.choice([2, 3, 5, 8]))
+            tiles_y = (H + 15) // 16
+            full = torch.zeros((tiles_y * 16, W, 3), device=img.device)
+            for r in range(step):
+                strip = R.render(cam, mk(tile_row_begin=r, tile_row_step=step, output_layout=2))
+                rows = list(range(r, tiles_y, step))
+                if rows:
+                    full.view(tiles_y, 16, W, 3)[r::step] = strip.view(len(rows), 16, W, 3)
+            assert torch.equal(full[:H], img), f"shards (step {step}) differ"
+            m = R.render(cam, mk(blend_impl=2)).cpu().numpy()
+            close(m, oimg)
+        except Exception as e:  # noqa: BLE001
+            fails += 1
+            print(f"FAIL {desc}: {type(e).__name__}: {str(e)[:300]}", flush=True)
+        cases += 1
+        if cases % 25 == 0:
+            print(f"{cases} cases, {fails} failures", flush=True)
+    print(f"done: {cases} cases, {fails} failures", flush=True)
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
