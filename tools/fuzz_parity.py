@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-n", type=int, default=60000)
+    ap.add_argument("--case-seed", type=int, default=None, help="replay one case (printed by a failure) with diagnostics")
     a = ap.parse_args()
 
     import gsr_amd  # noqa: F401
@@ -40,11 +41,13 @@ def main():
         if d.size >= 300_000:
             assert psnr(x, ref) >= 100.0, f"psnr {psnr(x, ref)}"
 
-    rng = np.random.default_rng(a.seed)
+    master = np.random.default_rng(a.seed)
     t_end = time.time() + a.seconds
     cases = fails = 0
     mk = renderer.make_options
-    while time.time() < t_end:
+    while time.time() < t_end and not (a.case_seed is not None and cases):
+        case_seed = int(master.integers(0, 1 << 62)) if a.case_seed is None else a.case_seed
+        rng = np.random.default_rng(case_seed)
         n = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, int(rng.integers(1, a.max_n))]))
         W = int(rng.choice([1, 15, 16, 17, 31, 33, 160, 333, 640, int(rng.integers(1, 1300))]))
         H = int(rng.choice([1, 15, 16, 17, 96, 197, 360, int(rng.integers(1, 800))]))
@@ -71,12 +74,19 @@ def main():
         cam, ocam = renderer.make_camera(*args), orc.camera(*args)
         degree = int(rng.choice([3, 3, 3, 0, 1, 2]))
         packed = utils.pack_gaussians(cols)
-        desc = f"n={n} {W}x{H} gen={gen.__name__} shift={shift} deg={degree} sf={sf}"
+        desc = f"case-seed={case_seed} n={n} {W}x{H} gen={gen.__name__} shift={shift} deg={degree} sf={sf}"
         try:
             scene = renderer.GaussianScene.from_packed(packed, sh_degree=degree) if degree != 3 else renderer.GaussianScene.from_packed(packed)
             R = renderer.Rasterizer(scene, max_pairs=int(rng.choice([0, 1000])) or None)
             img, T = R.render(cam, return_T=True)
             oimg, oT, _ = orc.render(packed, ocam, sh_degree=degree, want_T=True)
+            if a.case_seed is not None:
+                d = np.abs(img.cpu().numpy().astype(np.float64) - oimg).max(2)
+                dT = np.abs(T.cpu().numpy().astype(np.float64) - oT)
+                print(desc)
+                print(f"pixels off by > 1e-5: {(d > 1e-5).sum()} of {d.size}; > 4.5e-3: {(d > 4.5e-3).sum()}; worst colour {d.max():.6f}, worst T {dT.max():.6f}")
+                for y, x in zip(*np.unravel_index(np.argsort(-d, axis=None)[:6], d.shape)):
+                    print(f"   pixel ({x},{y}) colour diff {d[y, x]:.6f}  T diff {dT[y, x]:.6f}  T oracle {oT[y, x]:.6f}")
             close(img.cpu().numpy(), oimg)
             close(T.cpu().numpy()[..., None], oT[..., None])
             assert torch.equal(R.render(cam), img), "not reproducible"
@@ -92,7 +102,15 @@ def main():
                     full.view(tiles_y, 16, W, 3)[r::step] = strip.view(len(rows), 16, W, 3)
             assert torch.equal(full[:H], img), f"shards (step {step}) differ"
             m = R.render(cam, mk(blend_impl=2)).cpu().numpy()
-            close(m, oimg)
+            if a.case_seed is not None:
+                dm = np.abs(m.astype(np.float64) - oimg).max(2)
+                print(f"matrix-pipe blend: pixels off by > 1e-5: {(dm > 1e-5).sum()}; > 4.5e-3: {(dm > 4.5e-3).sum()}; worst {dm.max():.6f}; stats {R.last_stats}")
+                for y, x in zip(*np.unravel_index(np.argsort(-dm, axis=None)[:8], dm.shape)):
+                    print(f"   pixel ({x},{y}) tile ({x // 16},{y // 16}) in-tile ({x % 16},{y % 16}) diff {dm[y, x]:.6f}  T oracle {oT[y, x]:.3e}")
+            try:
+                close(m, oimg)
+            except AssertionError as e:
+                raise AssertionError(f"matrix-pipe blend: {e}") from None
         except Exception as e:  # noqa: BLE001
             fails += 1
             print(f"FAIL {desc}: {type(e).__name__}: {str(e)[:300]}", flush=True)
