@@ -111,6 +111,40 @@ def main():
                 close(m, oimg)
             except AssertionError as e:
                 raise AssertionError(f"matrix-pipe blend: {e}") from None
+            # -- the other modes, each against an exact property or the oracle ----------------------------------
+            assert torch.equal(R.render(cam, mk(output_layout=1)), img.transpose(0, 1)), "layout 1 is not the transpose"
+            nc = R.render(cam, mk(reference_compat=False))
+            assert torch.equal(nc[: H - 1, : W - 1], img[: H - 1, : W - 1]), "non-compat differs inside the frame"
+            eo = float(rng.choice([1e-4, 1e-2]))
+            assert float((R.render(cam, mk(early_out_T=eo)) - img).abs().max()) <= eo * 1.01 + 1e-6, "early-out bound"
+            cam2 = renderer.make_camera(pose.qvec, np.asarray(pose.tvec) + np.array([0.05, -0.02, 0.1]), *args[2:])
+            b = R.render_batch([cam, cam2, cam])
+            assert torch.equal(b[0], img) and torch.equal(b[2], img) and torch.equal(b[1], R.render(cam2)), "batch"
+            assert torch.equal(renderer.Rasterizer(scene, overlap=True).render(cam), img), "two-stream schedule"
+            if degree == 3 and n <= 200_000:
+                pre = orc.preprocess(packed, ocam)
+                dbg = R.preprocess_debug(cam)
+                for k in ("tile_bboxes", "pixel_bboxes"):
+                    got = dbg[k].cpu().numpy()
+                    bad = np.flatnonzero((got != pre[k]).any(1))
+                    if a.case_seed is not None and len(bad):
+                        for i in bad[:5]:
+                            print(f"   {k}[{i}]: hip {got[i]} oracle {pre[k][i]}  cov2d hip {dbg['cov2d'][i].cpu().numpy().ravel()} oracle {pre['cov2d'][i].ravel()}"
+                                  f"  mean hip {dbg['screen_means'][i].cpu().numpy()} oracle {pre['screen_means'][i]}  z {pre['cam_means'][i][2]}")
+                    # the rects are floor/ceil of fp32 expressions: exp/sqrt may differ by an ulp between ocml and libm, which
+                    # moves a rect edge by one tile for the rare gaussian sitting on the step
+                    assert len(bad) <= max(1, 2e-5 * n), f"{k}: {len(bad)} of {n} differ from the oracle"
+                    assert np.abs(got[bad] - pre[k][bad]).max(initial=0) <= (1 if k == "tile_bboxes" else 16), f"{k} off by more than one tile"
+                order = orc.depth_order(pre["cam_means"])
+                k = int(rng.integers(0, max(1, min(n, 2000))))
+                screen, _, _ = orc.composite(order, pre, W, H, limit=k)
+                if k > 0:
+                    close(R.render(cam, mk(draw_limit=k)).cpu().numpy(), screen.transpose(1, 0, 2))
+            half = renderer.Rasterizer(renderer.GaussianScene.from_packed(packed, sh_degree=degree, sh_half=True))
+            h = half.render(cam)
+            assert torch.equal(half.render(cam, mk(no_footprint_cull=True)), h), "fp16 SH: culling changes bits"
+            if float(img.abs().max()) > 0:
+                assert psnr(h.cpu().numpy(), img.cpu().numpy()) >= 60.0, "fp16 SH storage below 60 dB"
         except Exception as e:  # noqa: BLE001
             fails += 1
             print(f"FAIL {desc}: {type(e).__name__}: {str(e)[:300]}", flush=True)
