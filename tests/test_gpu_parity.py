@@ -451,3 +451,61 @@ def test_matrix_pipe_keeps_gaussians_at_their_peak(G):
     b = R.render(cam, G.renderer.make_options(blend_impl=2))
     d = (a - b).abs().amax(2)
     assert float(d.max()) <= 4.5e-3 and int((d > 1e-5).sum()) <= 1e-4 * d.numel(), (float(d.max()), int((d > 1e-5).sum()))
+
+
+def test_c_abi_rejects_bad_arguments(G):
+    """Error behaviour of the boundary (include/gsr.h): a negative GsrStatus plus gsr_last_error() text, nothing enqueued,
+    and the workspace / output untouched — never a fault on the device."""
+    import ctypes as C
+
+    from gsr_amd import _lib
+    from gsr_amd._lib import lib
+
+    cols, cam, _ = _medium(G, n=5_000, W=160, H=96)
+    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
+    ref = R.render(cam)
+    ws = R._workspace(cam.width, cam.height)
+    sc, mk = R.scene.c_struct(), G.renderer.make_options
+    out = torch.full_like(ref, 7.0)
+    sp = int(torch.cuda.current_stream().cuda_stream)
+
+    def call(scene=sc, camera=cam, opts=None, max_pairs=R.max_pairs, wsp=ws.data_ptr(), wsn=ws.numel(), o=out.data_ptr()):
+        opts = opts or mk()
+        return lib.gsr_render_forward(C.byref(scene), C.byref(camera), C.byref(opts), max_pairs, wsp, wsn, o, None, sp)
+
+    def bad_opts(**kw):
+        o = mk()
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
+
+    def bad_cam(**kw):
+        c = type(cam).from_buffer_copy(cam)
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+
+    def bad_scene(**kw):
+        s = type(sc).from_buffer_copy(sc)
+        for k, v in kw.items():
+            setattr(s, k, v)
+        return s
+
+    cases = {
+        "short workspace": dict(wsn=ws.numel() // 2), "null workspace": dict(wsp=None), "null output": dict(o=None),
+        "negative max_pairs": dict(max_pairs=-1), "zero width": dict(camera=bad_cam(width=0)), "negative height": dict(camera=bad_cam(height=-3)),
+        "row begin >= step": dict(opts=bad_opts(tile_row_begin=3, tile_row_step=3)), "negative row step": dict(opts=bad_opts(tile_row_step=-1)),
+        "bad layout": dict(opts=bad_opts(output_layout=5)), "bad dtype": dict(opts=bad_opts(output_dtype=2)),
+        "negative draw_limit": dict(opts=bad_opts(draw_limit=-1)), "negative n": dict(scene=bad_scene(n=-1)),
+        "null means": dict(scene=bad_scene(means=None)), "misaligned sh": dict(scene=bad_scene(sh=sc.sh + 4)),
+        "bad sh degree": dict(scene=bad_scene(sh_degree=4)), "bad sh dtype": dict(scene=bad_scene(sh_dtype=9)),
+    }
+    for name, kw in cases.items():
+        rc = call(**kw)
+        assert rc < 0, f"{name}: status {rc}"
+        assert lib.gsr_last_error(), name
+    torch.cuda.synchronize()
+    assert bool((out == 7.0).all()), "a rejected call wrote to the output"
+    assert call() == 0 and torch.equal(out, ref)   # and the library is still usable
+    with pytest.raises(_lib.GsrError):
+        _lib.workspace_bytes(10, 0, 10, 10)
