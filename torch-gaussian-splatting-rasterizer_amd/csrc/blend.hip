@@ -25,8 +25,9 @@
 // most of their gaussians, hit the same L2, and heavy image regions are spread over all XCDs.
 //
 // Roofline: algorithmic bytes = 40 per consumed entry (4 id + 36 record) + 12 per pixel
-// + 8 per tile range.  At ~20 VALU issues per (pixel, entry) evaluation the kernel is VALU/exp bound,
-// not HBM bound; both fractions are reported by bench.py.
+// + 8 per tile range.  The kernel is bound on-chip, not by HBM: ~21 VALU issues per evaluated (quadrant, entry) and three
+// wave-wide LDS broadcast reads of its record (10 LDS cycles; the CU's one LDS pipe is 72 % busy).  Removing VALU work
+// alone does not move it (DESIGN.md §5 lists the variants); bench.py reports the HBM fraction and the VALU issue fraction.
 #include "gsr_internal.h"
 #include "blend_args.h"
 #include "footprint.h"
@@ -35,7 +36,7 @@ namespace gsr {
 
 
 // one (pixel, entry) evaluation; g = {mean_x, mean_y}, c = {A, B, C, -}, o = {log2(opacity), r, g, b}.
-// ~16 VALU issues: the kernel is VALU-bound (tools/valu_microbench.hip prices them), so every one counts:
+// 17 VALU issues (tools/valu_microbench.hip prices them):
 //   - log2(opacity) rides in the quadratic's constant term: alpha = 2^p with p = power + L, and the reference's
 //     `power <= 0` becomes p <= L;
 //   - T*(1-alpha) is evaluated as T - alpha*T, reusing the product the colour update needs.
