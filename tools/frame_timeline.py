@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
 """Print the per-dispatch timeline of one steady-state frame from a rocprofv3 --kernel-trace CSV.
-usage: tools/frame_timeline.py <..._kernel_trace.csv> [frame_index_from_end=5]"""
+usage: tools/frame_timeline.py <..._kernel_trace.csv> [k | +k]     k (default 5): k-th frame from the end; +k: k-th from the start.
+Note for bench.py traces: the frames at the END of a run belong to its per-stage timing loop, which records an event between
+the three stages (a ~6 us bubble each); frames of the timed loop are free of them -- pick those with +k."""
 import csv
 import sys
 
 
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
-    back = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    arg = sys.argv[2] if len(sys.argv) > 2 else "5"
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     starts = [i for i, r in enumerate(rows) if "preprocess_kernel" in r["Kernel_Name"]]
-    s, e = starts[-back], starts[-back + 1]
+    if arg.startswith("+"):
+        s, e = starts[int(arg)], starts[int(arg) + 1]
+    else:
+        s, e = starts[-int(arg)], starts[-int(arg) + 1]
     t0 = int(rows[s]["Start_Timestamp"])
     prev_end = None
     total = 0.0

@@ -24,7 +24,7 @@ def main():
     os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
     shutil.copy(os.path.join(src, "trace_kernel_stats.csv"), out + "_kernel_stats.csv")
     tl = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "frame_timeline.py"),
-                         os.path.join(src, "trace_kernel_trace.csv")], capture_output=True, text=True).stdout
+                         os.path.join(src, "trace_kernel_trace.csv"), "+20"], capture_output=True, text=True).stdout  # a frame of the timed loop
     open(out + "_frame_timeline.txt", "w").write(tl)
     pmc = {}
     for f in sorted(glob.glob(os.path.join(src, "pmc_*_counter_collection.csv"))):

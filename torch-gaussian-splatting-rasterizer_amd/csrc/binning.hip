@@ -223,12 +223,12 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
 }
 
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t *__restrict__ pkey, const FrameCtrl *ctrl,
-                                                          uint2 *__restrict__ ranges, int n_tiles)
+                                                          uint2 *__restrict__ ranges, int n_tiles, uint32_t stride)
 {
-    // four keys per thread from one 16-B load; only the two keys flanking the group are read a second time
+    // four keys per thread from one 16-B load; only the two keys flanking the group are read a second time.
+    // stride = threads in the grid, passed in: gridDim / blockDim would pull in the 256-B hidden kernarg block
     const uint32_t n = ctrl->n_pairs;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; 4ull * t < n; t += stride) {
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; 4ull * t < n; t += stride) {
         const uint32_t i = 4u * t;
         uint32_t k[6];  // k[0] = key before the group, k[1..4] = the group, k[5] = key after it
         if (i + 4 <= n) {
@@ -300,7 +300,8 @@ int launch_tile_ranges(const Workspace &ws, int pair_buf, hipStream_t s)
     }
     if (ws.max_pairs <= 0) return GSR_OK;
     const int grid = (int)std::min<int64_t>((ws.max_pairs + 1023) / 1024, 8192);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(grid), dim3(256), 0, s, ws.pkey[pair_buf], ws.ctrl, ws.ranges, n_tiles);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(grid), dim3(256), 0, s, ws.pkey[pair_buf], ws.ctrl, ws.ranges, n_tiles,
+                       (uint32_t)grid * 256u);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
     // so workgroup 0 clears the counters here (a hipMemsetAsync costs two blit kernels and a dispatch bubble, ~20 us)
     if (blockIdx.x == 0)
         for (int w = threadIdx.x; w < ctrl_reset_words; w += 256) ctrl_words[w] = 0u;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // the literal, not blockDim.x: that would pull in the hidden kernarg block
     if (i >= sc.n) return;
     // (the gaussian id is not written: pass 0 of the depth sort synthesises the identity payload, 8 B per gaussian less traffic)
     const float p[3] = {sc.means[3 * i], sc.means[3 * i + 1], sc.means[3 * i + 2]};
@@ -200,7 +200,7 @@ template <bool SH16>
 __global__ __launch_bounds__(256) void color_kernel(GsrScene sc, float cx, float cy, float cz, const unsigned char *__restrict__ vis,
                                                     GaussRec *__restrict__ rec)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // the literal, not blockDim.x: that would pull in the hidden kernarg block
     if (i >= sc.n || !vis[i]) return;
     float sh[48];
     if (SH16) load_sh48_f16(sc.sh, i, sh);
