@@ -3,18 +3,22 @@
 
   python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
 
-A step = one complete 1920x1080 frame of the synthetic stand-in for MipNeRF-360 'garden'
-(BASELINE.json configs[1]; SURVEY.md §8(d): mip360_like(5_834_784, seed 360), ring camera 0), fp32,
-reference_compat, no early termination: preprocess -> depth sort -> tile binning -> blend, scene resident
-in HBM before the timed region.  With N > 1 the SAME frame is sharded by interleaved tile rows over the N
-GPUs and gathered to rank 0 over RCCL (strong scaling: total work per frame fixed).
+A step = one complete 1920x1080 frame of the synthetic stand-in for MipNeRF-360 'bicycle' — the scene BASELINE.json's
+metric is quoted on (mip360_like(6_131_954, seed 361), ring camera 0) — in the reference's own
+arithmetic: fp32 coefficients, fp32 frame, reference_compat, every gaussian blended (no approximate early termination):
+preprocess -> depth sort -> tile binning -> blend, scene resident in HBM before the timed region.  With N > 1 the SAME
+frame is sharded by interleaved tile rows over the N GPUs and gathered to rank 0 over RCCL (strong scaling: total work
+per frame fixed).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      HBM roofline of the dominant kernel (blend): algorithmic bytes 40*E + 12*P + 8*tiles per
-                launch / its measured average duration (HIP events on the launch stream) vs 8 TB/s
+  roofline      HBM roofline of the dominant kernel (blend): algorithmic bytes 40*E + 12*P + 8*tiles per launch / its
+                measured average duration (HIP events on the launch stream) vs 8 TB/s, plus the figures of the pipes
+                that actually limit it (VALU issue, LDS) from the committed rocprofv3 counters
   cpu_baseline  the reference's per-gaussian torch loop, ported (oracle/torch_loop.py), timed on this host on a
                 bounded subsample of the same frame and extrapolated to the frame
-and extras (PSNR of the timed configuration against the CPU oracle at full size, per-stage times, counters).
+and, as extra keys that are never `value`: PSNR of the timed configuration against the CPU oracle at full size,
+per-stage times, counters, and three more legs on the same GPU — `configs2` (BASELINE configs[2]: the same scene with fp16
+SH storage and a bf16 frame store), `early_out` (blend stops a wave at T < 1e-4) and `garden` (configs[1] stand-in).
 """
 from __future__ import annotations
 
@@ -33,13 +37,16 @@ import torch
 
 WORKLOADS = {
     # name: (generator, n, seed, W, H, description)
+    "bicycle": ("mip360_like", 6_131_954, 361, 1920, 1080, "synthetic stand-in for MipNeRF-360 bicycle (the metric's scene; configs[2]'s storage options are the `configs2` leg)"),
     "garden": ("mip360_like", 5_834_784, 360, 1920, 1080, "synthetic stand-in for MipNeRF-360 garden (configs[1])"),
-    "bicycle": ("mip360_like", 6_131_954, 361, 1920, 1080, "synthetic stand-in for MipNeRF-360 bicycle (configs[2]): fp16 SH storage; "
-                "blend accumulators stay fp32 (bf16 accumulators measure 41 dB < the 50 dB bar, SURVEY.md §7)"),
     "box4k": ("uniform_box", 20_000_000, 20, 3840, 2160, "20M uniform gaussians at 4K (configs[4])"),
 }
+METRIC = {
+    "bicycle": "frames/sec @1080p + PSNR vs torch ref, MipNeRF-360 bicycle, 1/2/4/8 GPUs",
+    "garden": "frames/sec @1080p + PSNR vs torch ref, MipNeRF-360 garden (configs[1]; NOT the headline scene), 1/2/4/8 GPUs",
+    "box4k": "frames/sec @4K, synthetic 20M gaussians (configs[4])",
+}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-FP32_PEAK_TFLOPS = 157.3
 
 
 def host_threads() -> int:
@@ -58,20 +65,19 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="garden", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="bicycle", choices=sorted(WORKLOADS))
     ap.add_argument("--gaussians", type=int, default=0, help="override the gaussian count (0 = the workload's)")
     ap.add_argument("--early-out-T", type=float, default=0.0)
-    ap.add_argument("--blend-impl", type=int, default=0, help="0/1 vector-ALU blend (reference-grade), 2 matrix-pipe blend")
-    ap.add_argument("--overlap", action="store_true", help="two streams: run the SH colour pass under the sorts (measured slower)")
-    ap.add_argument("--sh-half", action="store_true", help="store SH coefficients as fp16 (implied by --workload bicycle)")
+    ap.add_argument("--blend-impl", type=int, default=0, help="0 default blend, 2 experimental matrix-pipe blend")
+    ap.add_argument("--sh-half", action="store_true", help="headline with SH coefficients stored as fp16 (default: fp32, the reference's type)")
+    ap.add_argument("--bf16-output", action="store_true", help="headline with the frame stored as bfloat16; accumulation stays fp32")
     ap.add_argument("--camera", type=int, default=0)
     ap.add_argument("--camera-set", default="single", choices=["single", "all"],
                     help="single: every step renders --camera; all: steps cycle over the whole camera set (configs[3])")
     ap.add_argument("--input_dir", default="", help="real data: MipNeRF-360 scene dir with sparse/0/{images,cameras}.bin")
     ap.add_argument("--trained_model_path", default="", help="real data: INRIA model dir (point_cloud/iteration_30000/point_cloud.ply)")
+    ap.add_argument("--legs", default="configs2,early_out,garden", help="extra legs at N=1 (comma list; '' = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bf16-output", action="store_true", help="store the frame as bfloat16 (configs[2]); accumulation stays fp32")
-    ap.add_argument("--no-early-out-leg", action="store_true", help="skip the extra T<1e-4 measurement (profiling runs)")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     return ap.parse_args()
@@ -96,14 +102,12 @@ def build_real_workload(args):
     return cols, cam_list, n, W, H, f"real data: {args.input_dir} + {args.trained_model_path}, {len(cam_list)} camera(s)"
 
 
-def build_workload(args):
+def build_workload(name, args, n_override=0):
     from gsr_amd import synthetic
 
-    if args.input_dir and args.trained_model_path:
-        return build_real_workload(args)
-    gen, n, seed, W, H, desc = WORKLOADS[args.workload]
-    if args.gaussians:
-        n = args.gaussians
+    gen, n, seed, W, H, desc = WORKLOADS[name]
+    if n_override:
+        n = n_override
     cols = getattr(synthetic, gen)(n, seed)
     if gen == "uniform_box":
         poses = [synthetic.box_camera()]
@@ -115,6 +119,32 @@ def build_workload(args):
     # on-disk convention: full-res = 2x, scale-factor 2
     cam_list = [(p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H) for p in poses]
     return cols, cam_list, n, W, H, desc
+
+
+def timed_frames(R, cams, opts, out, steps, warmup, dev):
+    """Single-GPU legs: `warmup` untimed frames, then `steps` frames between two device synchronisations."""
+    for i in range(warmup):
+        R.enqueue(cams[i % len(cams)], opts, out=out)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        R.enqueue(cams[i % len(cams)], opts, out=out)
+    torch.cuda.synchronize(dev)
+    return time.perf_counter() - t0
+
+
+def psnr_pair(img, ref):
+    mse = float(np.mean((img.astype(np.float64) - ref) ** 2))
+    return (None if mse == 0 else 10 * np.log10(1.0 / mse)), float(np.abs(img - ref).max())
+
+
+def pmc_profile(workload):
+    """Per-launch rocprofv3 counters of the blend kernel, committed under profiles/ (tools/summarize_profiles.py)."""
+    tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(tfile)).get(workload, {})
+    except Exception:
+        return {}
 
 
 def main():
@@ -144,19 +174,22 @@ def main():
     from gsr_amd import dist as gdist
     from gsr_amd import renderer, utils
 
-    cols, cam_list, n, W, H, desc = build_workload(args)
+    real = bool(args.input_dir and args.trained_model_path)
+    if real:
+        cols, cam_list, n, W, H, desc = build_real_workload(args)
+    else:
+        cols, cam_list, n, W, H, desc = build_workload(args.workload, args, args.gaussians)
     cam_args = cam_list[0]
     packed = utils.pack_gaussians(cols)
     del cols
-    sh_half = args.sh_half or args.workload == "bicycle"
-    scene = renderer.GaussianScene.from_packed(packed, device=dev, sh_half=sh_half)
+    scene = renderer.GaussianScene.from_packed(packed, device=dev, sh_half=args.sh_half)
     cams = [renderer.make_camera(*c) for c in cam_list]
     cam = cams[0]
     ncam = len(cams)
     plan = gdist.TileRowPlan(H, W, world)
     out_dtype = torch.bfloat16 if args.bf16_output else torch.float32
     fg = gdist.FrameGather(plan, rank, dev, dtype=out_dtype)
-    R = renderer.Rasterizer(scene, overlap=args.overlap)
+    R = renderer.Rasterizer(scene)
     state1 = {"i": 0}
     if world == 1:  # no sharding: blend straight into the frame
         opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl, output_bf16=args.bf16_output)
@@ -221,23 +254,22 @@ def main():
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         result = {
-            "metric": "frames/sec @1080p + PSNR vs torch ref, MipNeRF-360 bicycle, 1/2/4/8 GPUs" if args.workload != "box4k"
-                      else "frames/sec @4K, synthetic 20M gaussians",
+            "metric": METRIC[args.workload] if not real else METRIC["bicycle"],
             "value": args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "gaussians": n, "width": W, "height": H,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32",  # the arithmetic type of the whole path; storage options are named in config
+            "data": "real" if real else "synthetic",
+            "config": {"workload": f"{'real' if real else args.workload}: {desc}", "gaussians": n, "width": W, "height": H,
                        "camera": args.camera if ncam == 1 else f"cycling over {ncam} cameras",
                        "sharding": f"tile rows interleaved over {world} GPU(s), RCCL gather to rank 0" if world > 1 else "none",
-                       "reference_compat": True, "early_out_T": args.early_out_T, "sh_storage": "f16" if sh_half else "f32",
+                       "reference_compat": True, "early_out_T": args.early_out_T, "sh_storage": "f16" if args.sh_half else "f32",
                        "frame_storage": "bf16 (fp32 accumulation)" if args.bf16_output else "f32",
-                       "blend_impl": "mfma" if args.blend_impl == 2 else "valu",
-                       "streams": "2 (SH colour pass under the sorts)" if args.overlap else 1},
+                       "blend_impl": "mfma (experimental)" if args.blend_impl == 2 else "valu"},
             "stats_rank0_shard": shard_stats,
         }
 
     # ---- rank 0: per-stage timing + roofline of ITS shard (the whole frame at N=1), outside the timed region; at N=1 also
-    # ---- PSNR vs the oracle, the early-out leg and the CPU baseline -------------------------------------------------------
+    # ---- PSNR vs the oracle, the extra legs and the CPU baseline -------------------------------------------------------
     if rank == 0:
         import ctypes as C
 
@@ -273,26 +305,28 @@ def main():
         if world > 1:
             tiles = len(plan.rows[rank]) * ((W + 15) // 16)
         blend_bytes = 40.0 * E + 12.0 * P + 8.0 * tiles
-        pre_bytes = (140.0 if sh_half else 236.0) * n + 64.0 * V
+        pre_bytes = (140.0 if args.sh_half else 236.0) * n + 64.0 * V
         achieved = blend_bytes / (stage[2] * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile) and world == 1:
-            try:
-                traffic = json.load(open(tfile)).get(args.workload, {}).get("blend_kernel_bytes_per_launch")
-            except Exception:
-                traffic = None
-        result["roofline"] = {"kernel": "gsr::blend_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                              "algorithmic_bytes_per_launch": blend_bytes, "avg_kernel_ms": stage[2],
-                              "note": "blend is bound on-chip in exact mode (VALU issue + LDS broadcast pipe 72 % busy, DESIGN.md §5; SURVEY.md §7 hard part 1): see valu_issue_frac; traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE from profiles/"}
-        # honesty figure: the blend is VALU-bound.  64 pixel evaluations per evaluated (quadrant, entry);
-        # rocprofv3 PMC (profiles/r1_pmc.json) counts 21.4 VALU wave-instructions per of them (17 in the inner loop + culling,
-        # staging).  Peak issue = one fp32 VALU wave-instruction per 2 cycles per SIMD (tools/valu_microbench.hip), 1024 SIMDs,
-        # 2.4 GHz; v_exp_f32 costs 4 and v_cmp/v_cndmask ~1.5 of those slots, so the pipe is fuller than this fraction says.
+        prof = pmc_profile(args.workload) if world == 1 else {}
+        result["roofline"] = {
+            "kernel": "gsr::blend_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": prof.get("blend_kernel_bytes_per_launch"),
+            "algorithmic_bytes_per_launch": blend_bytes, "avg_kernel_ms": stage[2],
+            "limiter": "on-chip: VALU issue + LDS reads (exact per-pixel evaluation: ~70 flop and 6.4 exp per algorithmic byte, "
+                       "SURVEY.md §7 hard part 1); HBM is not the bound, frac is the contract figure",
+            "note": "traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction, an upper bound for gathered 48-B records) + WRITE_SIZE, "
+                    "separate --pmc passes, from profiles/",
+        }
+        # honesty figures: pixel evaluations, and the two pipes that bound the kernel, priced from the committed
+        # counters: VALU wave-instructions per launch at one fp32 issue per 2 cycles per SIMD (1024 SIMDs), LDS-array cycles per
+        # launch (SQ_LDS_IDX_ACTIVE) over the kernel's cycles (GRBM_GUI_ACTIVE / 8 XCDs).  Both scale with evaluated entries.
         evals = 64.0 * st["wave_entries"]
         result["roofline"]["pixel_evaluations"] = evals
-        result["roofline"]["valu_issue_frac"] = st["wave_entries"] * 21.4 / (stage[2] * 1e-3) / (1024 * 1.2e9)
+        if prof.get("valu_insts_per_wave_entry"):
+            clk = prof.get("clock_ghz", 2.0)
+            result["roofline"]["valu_issue_frac"] = st["wave_entries"] * prof["valu_insts_per_wave_entry"] * 2.0 / (stage[2] * 1e-3) / (1024 * clk * 1e9)
+        if prof.get("lds_busy_frac") is not None:
+            result["roofline"]["lds_busy_frac_profiled"] = prof["lds_busy_frac"]
         result["stage_ms"] = {"preprocess": stage[0], "bin_sort": stage[1], "blend": stage[2]}
         result["stage_hbm_gbs"] = {"preprocess": pre_bytes / (stage[0] * 1e-3) / 1e9}
         result["stats"] = st
@@ -300,29 +334,39 @@ def main():
             result["roofline"]["note"] = "rank 0's shard (interleaved tile rows); " + result["roofline"]["note"]
 
     if rank == 0 and world == 1:
-        # the same frame with the usual 3DGS saturation cut-off (INRIA's T < 1e-4), timed the same way: the headline stays the
-        # exact mode (no blend work skipped, reference semantics Q5); this line shows what north_star's "ballot early-out on
-        # saturated alpha" buys inside its PSNR >= 50 dB tolerance
-        eo_img = None
-        if args.early_out_T == 0.0 and not args.no_early_out_leg:
-            eo_T = 1e-4
-            eo_opts = renderer.make_options(early_out_T=eo_T, blend_impl=args.blend_impl)
-            eo_out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
-            for _ in range(min(args.warmup, 5) + 1):
-                R.enqueue(cam, eo_opts, out=eo_out)
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            for i in range(args.steps):
-                R.enqueue(cams[i % ncam], eo_opts, out=eo_out)
-            torch.cuda.synchronize(dev)
-            eo_elapsed = time.perf_counter() - t1
-            R.enqueue(cam, eo_opts, out=eo_out)
-            eo_stats = R.stats()
-            eo_img = eo_out.cpu().numpy()
-            result["early_out"] = {"early_out_T": eo_T, "frames_per_s": args.steps / eo_elapsed,
-                                   "ms_per_step": 1e3 * eo_elapsed / args.steps, "wave_entries": eo_stats["wave_entries"],
-                                   "fetched_entries": eo_stats["fetched_entries"],
+        legs = [x for x in args.legs.split(",") if x] if not real else []
+        leg_imgs = {}
+        steps_leg, warm_leg = args.steps, min(args.warmup, 5) + 1
+        leg_out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+
+        # (1) the same frame with the usual 3DGS saturation cut-off (INRIA's T < 1e-4): the headline stays the exact mode (no
+        # blend work skipped, reference semantics Q5); this shows what north_star's "ballot early-out on saturated alpha" buys
+        # inside its PSNR >= 50 dB tolerance
+        if "early_out" in legs and args.early_out_T == 0.0:
+            eo_opts = renderer.make_options(early_out_T=1e-4, blend_impl=args.blend_impl)
+            el = timed_frames(R, cams, eo_opts, leg_out, steps_leg, warm_leg, dev)
+            R.enqueue(cam, eo_opts, out=leg_out)
+            s = R.stats()
+            leg_imgs["early_out"] = leg_out.cpu().numpy()
+            result["early_out"] = {"early_out_T": 1e-4, "frames_per_s": steps_leg / el, "ms_per_step": 1e3 * el / steps_leg,
+                                   "wave_entries": s["wave_entries"], "fetched_entries": s["fetched_entries"],
                                    "note": "not the headline: same workload with the blend stopping a wave once T < 1e-4 for its 64 pixels"}
+
+        # (2) BASELINE configs[2]: fp16 SH storage + bf16 frame store (accumulation stays fp32: bf16 accumulators measure 41 dB,
+        # below the 50 dB bar).  PSNR below is against the fp32 oracle of the fp32 coefficients.
+        if "configs2" in legs and not args.sh_half:
+            scene_h = renderer.GaussianScene.from_packed(packed, device=dev, sh_half=True)
+            Rh = renderer.Rasterizer(scene_h, max_pairs=R.max_pairs)
+            h_opts = renderer.make_options(output_bf16=True)
+            h_out = torch.empty((H, W, 3), dtype=torch.bfloat16, device=dev)
+            el = timed_frames(Rh, cams, h_opts, h_out, steps_leg, warm_leg, dev)
+            Rh.enqueue(cam, h_opts, out=h_out)
+            s = Rh.stats()
+            leg_imgs["configs2"] = h_out.float().cpu().numpy()
+            result["configs2"] = {"frames_per_s": steps_leg / el, "ms_per_step": 1e3 * el / steps_leg, "sh_storage": "f16",
+                                  "frame_storage": "bf16 (fp32 accumulation)", "fetched_entries": s["fetched_entries"],
+                                  "note": "not the headline: BASELINE configs[2] storage options on the same scene and camera"}
+            del Rh, scene_h, h_out
 
         oracle_img = None
         pre = order = None
@@ -340,14 +384,9 @@ def main():
                 screen, _, drawn = orc.composite(order, pre, W, H, threads=threads)
                 t_comp = time.perf_counter() - t1
                 oracle_img = screen.transpose(1, 0, 2)
-                img = frame.float().cpu().numpy()
-                mse = float(np.mean((img.astype(np.float64) - oracle_img) ** 2))
-                result["psnr_vs_oracle_db"] = None if mse == 0 else 10 * np.log10(1.0 / mse)
-                result["max_abs_vs_oracle"] = float(np.abs(img - oracle_img).max())
-                if eo_img is not None:
-                    mse = float(np.mean((eo_img.astype(np.float64) - oracle_img) ** 2))
-                    result["early_out"]["psnr_vs_oracle_db"] = None if mse == 0 else 10 * np.log10(1.0 / mse)
-                    result["early_out"]["max_abs_vs_oracle"] = float(np.abs(eo_img - oracle_img).max())
+                result["psnr_vs_oracle_db"], result["max_abs_vs_oracle"] = psnr_pair(frame.float().cpu().numpy(), oracle_img)
+                for k, im in leg_imgs.items():
+                    result[k]["psnr_vs_oracle_db"], result[k]["max_abs_vs_oracle"] = psnr_pair(im, oracle_img)
                 result["cpu_oracle_c"] = {"frame_s": t_pre + t_comp, "threads": threads, "drawn": int(drawn),
                                           "note": "oracle/gsr_oracle.c, OpenMP over x bands; checker, not the baseline"}
         if not args.no_cpu_baseline:
@@ -358,12 +397,33 @@ def main():
             s = torch_loop.timed_sample(pre, order, W, H, budget_s=args.cpu_budget_s, max_gaussians=400_000)
             result["cpu_baseline"] = {
                 "value": 1.0 / s["extrapolated_frame_s"], "unit": "frames/s", "cores": cores, "kind": "port",
-                "sample": (f"reference per-gaussian torch loop (oracle/torch_loop.py): uniform random sample of {s['sampled']} of the "
+                "sample": (f"reference per-gaussian torch loop (oracle/torch_loop.py, checked against the reference's frames in "
+                           f"tests/test_oracle_golden.py): uniform random sample of {s['sampled']} of the "
                            f"frame's {s['total_iterations']} loop iterations, {s['seconds']:.1f} s; {s['drawn']} drawn at "
                            f"{1e3 * s['s_per_drawn']:.3f} ms each, skipped at {1e6 * s['s_per_skipped']:.1f} us each; frame = "
                            f"{s['total_drawn']} drawn + rest skipped, extrapolated {s['extrapolated_frame_s']:.0f} s "
                            f"(excludes the vectorised preprocessing)"),
             }
+            result["vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]  # not vs_baseline: no published number exists
+        del pre, order, oracle_img, leg_imgs
+
+        # (3) BASELINE configs[1]: the garden stand-in, fp32, exact — last, once the headline scene's host arrays are gone
+        if "garden" in legs and args.workload != "garden":
+            del R, scene, packed
+            torch.cuda.empty_cache()
+            gcols, gcam_list, gn, _, _, gdesc = build_workload("garden", args)
+            gscene = renderer.GaussianScene.from_columns(gcols, device=dev)
+            del gcols
+            gcams = [renderer.make_camera(*c) for c in gcam_list]
+            Rg = renderer.Rasterizer(gscene)
+            g_opts = renderer.make_options()
+            Rg.max_pairs = max(Rg.fit_pairs(c, g_opts) for c in gcams)
+            el = timed_frames(Rg, gcams, g_opts, leg_out, steps_leg, warm_leg, dev)
+            Rg.enqueue(gcams[0], g_opts, out=leg_out)
+            s = Rg.stats()
+            result["garden"] = {"frames_per_s": steps_leg / el, "ms_per_step": 1e3 * el / steps_leg, "gaussians": gn,
+                                "stats": s, "note": "not the headline: BASELINE configs[1] stand-in (" + gdesc + "), fp32, exact; "
+                                "its oracle parity is tests/test_gpu_configs.py"}
 
     if rank == 0:
         print(json.dumps(result), flush=True)

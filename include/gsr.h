@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 100 /* 0.1.0 */
+#define GSR_VERSION 200 /* 0.2.0: gsr_preprocess_geometry/_color removed (measured slower), gsr_read_stats takes a non-const workspace */
 
 typedef enum GsrStatus {
     GSR_OK = 0,
@@ -41,6 +41,7 @@ typedef enum GsrStatus {
 #define GSR_CULL_Z 0.2f              /* rasterize.py:377 */
 #define GSR_LOWPASS 0.3f             /* rasterize.py:249-250 */
 #define GSR_EIG_FLOOR 0.1f           /* rasterize.py:172,175 */
+#define GSR_MAX_PAIRS 0xFFFFE000ll   /* largest max_pairs: pairs are indexed in 32 bits, one 4096-pair sort tile of headroom */
 
 /* Camera-independent trained gaussians, exactly the values stored in the INRIA .ply
  * (rasterize.py:98-106,354-358; utils.py:10-31).  Row-major dense arrays. */
@@ -142,16 +143,6 @@ int gsr_workspace_bytes(int64_t n, int32_t width, int32_t height, int64_t max_pa
 int gsr_preprocess(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
                    size_t workspace_bytes, const GsrDebugOut *debug /* [host], may be NULL */, void *stream);
 
-/* Stage 1 in two halves, for callers that overlap them with stage 2: geometry decides visibility and writes everything
- * but the colour (44 B read per gaussian); colour evaluates the SH of the gaussians geometry kept (192 B each).
- * Nothing before gsr_blend reads the colour, so gsr_preprocess_color may run on a SECOND stream concurrently with
- * gsr_bin_sort (small, latency-bound launches): order it after gsr_preprocess_geometry and before gsr_blend with events.
- * gsr_preprocess_geometry + gsr_preprocess_color == gsr_preprocess, bit for bit. */
-int gsr_preprocess_geometry(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
-                            size_t workspace_bytes, void *stream);
-int gsr_preprocess_color(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
-                         size_t workspace_bytes, void *stream);
-
 /* Stage 2 — depth order (rasterize.py:424-425, ties broken by gaussian index) and 16x16 tile binning:
  * radix sort of the visible gaussians by depth, pair emission in depth order, stable radix sort by tile,
  * per-tile [begin,end) ranges.  Needs gsr_preprocess on the same workspace first. */
@@ -179,10 +170,10 @@ int gsr_render_batch(const GsrScene *scene, const GsrCamera *cams /* [host] */, 
                      void *stream);
 
 /* Totals the blend's per-workgroup counters (one small kernel on `stream`: wave_entries / fetched_entries describe the
- * LAST gsr_blend of the frame, 0 if none ran), copies the frame counters to host memory and waits for the stream.
- * Returns GSR_ERR_PAIR_OVERFLOW if the frame overflowed max_pairs.  `workspace` is const in the sense that no frame
- * data changes; the two totals are written into its counter block. */
-int gsr_read_stats(const void *workspace, size_t workspace_bytes, GsrStats *out /* [host] */, void *stream);
+ * LAST gsr_blend of the frame, 0 if none ran; the two totals are written into the workspace's counter block, no frame
+ * data changes), copies the frame counters to host memory and waits for the stream.
+ * Returns GSR_ERR_PAIR_OVERFLOW if the frame overflowed max_pairs. */
+int gsr_read_stats(void *workspace, size_t workspace_bytes, GsrStats *out /* [host] */, void *stream);
 
 /* Stand-alone helpers behind the reference's helper functions (same maths as inside gsr_preprocess). */
 /* sh_to_rgb, spherical_harmonics.py:27-73 */

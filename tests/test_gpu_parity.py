@@ -213,18 +213,6 @@ def test_very_wide_frame_uses_the_gathered_rect_path(G):
     assert_frames_close(img, oimg)
 
 
-def test_split_stage1_on_two_streams_is_bit_identical(G):
-    """gsr_preprocess_geometry + gsr_preprocess_color (second stream, under the sorts) == the fused gsr_preprocess."""
-    cols, cam, _ = _medium(G)
-    scene = G.renderer.GaussianScene.from_columns(cols)
-    a = G.renderer.Rasterizer(scene, overlap=False).render(cam)
-    R = G.renderer.Rasterizer(scene, overlap=True)
-    for _ in range(3):
-        assert torch.equal(R.render(cam), a)
-    half = G.renderer.GaussianScene.from_columns(cols, sh_half=True)
-    assert torch.equal(G.renderer.Rasterizer(half, overlap=True).render(cam), G.renderer.Rasterizer(half, overlap=False).render(cam))
-
-
 def test_reference_screen_layout(G):
     g = load_golden("f2_small.npz")
     cam, _ = _cams(G, g)
@@ -509,3 +497,67 @@ def test_c_abi_rejects_bad_arguments(G):
     assert call() == 0 and torch.equal(out, ref)   # and the library is still usable
     with pytest.raises(_lib.GsrError):
         _lib.workspace_bytes(10, 0, 10, 10)
+
+
+def _ctrl_word(R, cam, byte_offset):
+    """A 32-bit word of the workspace's counter block (gsr_internal.h FrameCtrl) — only the tests peek in there."""
+    ws = R._workspace(cam.width, cam.height)
+    torch.cuda.synchronize()
+    return int(ws[byte_offset: byte_offset + 4].view(torch.int32).item())
+
+
+SORT_PASSES_OFFSET = 40 + 512 * 4 + 8     # FrameCtrl: 40-byte GsrStats head, digit_tot[512], stats_off, stats_slots
+
+
+def test_depth_sort_plans_its_passes_from_the_key_range(G):
+    """sort.hip: the depth sort runs on key - bits(0.2f) and only over the bits the frame uses.  An ordinary scene (depths
+    0.2 .. 64) sorts in 3 passes (9 + 9 + 9 bits); the same scene blown up 1000x needs the fourth.  Both against the oracle,
+    and the order is exact in both (a wrong digit split would scramble the draw order)."""
+    cols, cam, ocam = _medium(G, n=120_000)
+    packed = G.utils.pack_gaussians(cols)
+    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(packed))
+    img = R.render(cam).cpu().numpy()
+    assert _ctrl_word(R, cam, SORT_PASSES_OFFSET) == 3
+    oimg, _ = G.orc.render(packed, ocam)
+    assert_frames_close(img, oimg)
+    far = {k: v.copy() for k, v in cols.items()}
+    for k in "xyz":
+        far[k] = (far[k] * np.float32(1000.0)).astype(np.float32)
+    for i in range(3):
+        far[f"scale_{i}"] = (far[f"scale_{i}"] + np.float32(np.log(1000.0) - 1.5)).astype(np.float32)
+    fpacked = G.utils.pack_gaussians(far)
+    Rf = G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(fpacked))
+    fimg = Rf.render(cam).cpu().numpy()
+    assert _ctrl_word(Rf, cam, SORT_PASSES_OFFSET) == 4 and Rf.last_stats["n_visible"] > 1000
+    foimg, _ = G.orc.render(fpacked, ocam)
+    assert_frames_close(fimg, foimg)
+    # the plan is per frame: the near scene on the far scene's workspace geometry goes back to 3 passes
+    assert torch.equal(R.render(cam), torch.from_numpy(img).to("cuda")) and _ctrl_word(R, cam, SORT_PASSES_OFFSET) == 3
+
+
+@pytest.mark.parametrize("name,prefix", [("medium", ""), ("f3_edge.npz", "a_"), ("f3_edge.npz", "b_")])
+def test_fused_binning_equals_the_emit_then_sort_path(G, monkeypatch, name, prefix):
+    """binning.hip: generating the pairs inside the first tile-sort pass (fused path) must give the very lists the legacy
+    path builds (emit in depth order, then the generic sort over all key bits): identical frames, T and counters —
+    whole frame, shards, progressive prefixes, a frame-covering gaussian (f3a), a frame not a multiple of 16 (f3b)."""
+    if name == "medium":
+        cols, cam, _ = _medium(G, n=150_000)
+    else:
+        g = load_golden(name)
+        cols = golden_columns(g)
+        cam, _ = _cams(G, g, prefix)
+    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
+    mk = G.renderer.make_options
+    variants = [mk(), mk(tile_row_begin=1, tile_row_step=3, output_layout=2), mk(draw_limit=37), mk(no_footprint_cull=True)]
+    fused = []
+    for o in variants:
+        img, T = R.render(cam, o, return_T=True)
+        fused.append((img.clone(), T.clone(), dict(R.last_stats)))
+    monkeypatch.setenv("GSR_LEGACY_BINNING", "1")
+    for o, (img, T, st) in zip(variants, fused):
+        limg, lT = R.render(cam, o, return_T=True)
+        assert torch.equal(limg, img) and torch.equal(lT, T)
+        for k in ("n_visible", "n_pairs", "n_pairs_bbox", "max_list_len", "fetched_entries", "wave_entries"):
+            assert R.last_stats[k] == st[k], k
+    monkeypatch.delenv("GSR_LEGACY_BINNING")
+    assert torch.equal(R.render(cam), fused[0][0])

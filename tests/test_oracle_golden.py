@@ -122,3 +122,22 @@ def test_f4_medium_regenerated_inputs():
     assert psnr(img[::4, ::4], g["decimated"]) >= 110.0
     np.testing.assert_allclose(img.astype(np.float64).sum(axis=(1, 2)), g["row_sums"], rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(img.astype(np.float64).sum(axis=(0, 2)), g["col_sums"], rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["f1_unit.npz", "f2_small.npz"])
+def test_torch_loop_port_reproduces_the_reference_frames(name):
+    """oracle/torch_loop.py is what bench.py times as cpu_baseline (kind "port"): the reference's per-gaussian loop
+    (rasterize.py:436-446, :255-305) re-stated in torch ops.  Same frame as the reference's own, same draw count."""
+    from oracle import torch_loop
+
+    g = load_golden(name)
+    cam = _cam(g)
+    pre = orc.preprocess(utils.pack_gaussians(golden_columns(g)), cam)
+    order = orc.depth_order(pre["cam_means"])
+    img, drawn = torch_loop.render(pre, order, cam.width, cam.height)
+    assert drawn == len(g["draw_order"])
+    assert psnr(img, g["image"]) >= 120.0, psnr(img, g["image"])
+    assert not img[-1].any() and not img[:, -1].any()           # Q1
+    # and the timed-sample estimator walks the same two classes of iterations
+    s = torch_loop.timed_sample(pre, order, cam.width, cam.height, budget_s=2.0, max_gaussians=500)
+    assert s["total_drawn"] == drawn and s["total_iterations"] == len(order) and s["sampled"] <= 500

@@ -21,6 +21,7 @@ GSR_ERR_BAD_ARG = -1
 GSR_ERR_WORKSPACE = -2
 GSR_ERR_PAIR_OVERFLOW = -3
 GSR_ERR_HIP = -4
+GSR_MAX_PAIRS = 0xFFFFE000  # include/gsr.h
 
 
 class GsrError(RuntimeError):
@@ -99,7 +100,7 @@ class GsrDebugOut(C.Structure):
 
 EXPORTS = [
     "gsr_version", "gsr_last_error", "gsr_default_options", "gsr_camera_setup", "gsr_workspace_bytes",
-    "gsr_preprocess", "gsr_preprocess_geometry", "gsr_preprocess_color", "gsr_bin_sort", "gsr_blend", "gsr_render_forward", "gsr_read_stats", "gsr_sh_to_rgb", "gsr_cov3d",
+    "gsr_preprocess", "gsr_bin_sort", "gsr_blend", "gsr_render_forward", "gsr_read_stats", "gsr_sh_to_rgb", "gsr_cov3d",
     "gsr_render_batch", "gsr_project_to_camera_space", "gsr_compute_2d_covariance", "gsr_compute_covering_bbox", "gsr_rasterize_gaussian",
 ]
 
@@ -121,8 +122,6 @@ def _load() -> C.CDLL:
     L.gsr_workspace_bytes.argtypes = [i64, i32, i32, i64, C.POINTER(sz)]
     L.gsr_preprocess.argtypes = [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrOptions), vp, sz,
                                  C.POINTER(GsrDebugOut), vp]
-    L.gsr_preprocess_geometry.argtypes = [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrOptions), vp, sz, vp]
-    L.gsr_preprocess_color.argtypes = [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrOptions), vp, sz, vp]
     L.gsr_bin_sort.argtypes = [i64, C.POINTER(GsrCamera), C.POINTER(GsrOptions), i64, vp, sz, vp]
     L.gsr_blend.argtypes = [i64, C.POINTER(GsrCamera), C.POINTER(GsrOptions), i64, vp, sz, vp, vp, vp]
     L.gsr_render_forward.argtypes = [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrOptions), i64, vp, sz, vp, vp, vp]

@@ -42,18 +42,19 @@ size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max
     ws->max_pairs = max_pairs;
     ws->tiles_x = (width + GSR_TILE - 1) / GSR_TILE;
     ws->tiles_y = (height + GSR_TILE - 1) / GSR_TILE;
-    ws->hist_blocks = (int)std::max((nn + SORT_THREADS * DEPTH_SORT_ITEMS - 1) / (SORT_THREADS * DEPTH_SORT_ITEMS),
-                                    (np + SORT_THREADS * PAIR_SORT_ITEMS - 1) / (SORT_THREADS * PAIR_SORT_ITEMS));
+    // row stride of the histogram table: tiles of the depth sort, tiles of the pair sort, gaussian blocks of the fused binning
+    ws->hist_blocks = (int)std::max({(nn + SORT_THREADS * DEPTH_SORT_ITEMS - 1) / (SORT_THREADS * DEPTH_SORT_ITEMS),
+                                     (np + SORT_THREADS * PAIR_SORT_ITEMS - 1) / (SORT_THREADS * PAIR_SORT_ITEMS),
+                                     (nn + PAIR_BLOCK - 1) / PAIR_BLOCK});
     ws->ctrl = static_cast<FrameCtrl *>(take(sizeof(FrameCtrl)));
     ws->rec = static_cast<GaussRec *>(take(sizeof(GaussRec) * nn));
     ws->rect = static_cast<ushort4 *>(take(sizeof(ushort4) * nn));
     for (int b = 0; b < 2; ++b) ws->key[b] = static_cast<uint32_t *>(take(4 * nn));
     for (int b = 0; b < 2; ++b) ws->val[b] = static_cast<uint32_t *>(take(4 * nn));
     for (int b = 0; b < 2; ++b) ws->rect8[b] = static_cast<uint32_t *>(take(4 * nn));
-    ws->vis = static_cast<unsigned char *>(take(nn));
     ws->blk_sum = static_cast<uint32_t *>(
         take(4 * ((std::max(nn, (size_t)ws->tiles_x * ws->tiles_y) + EMIT_THREADS - 1) / EMIT_THREADS + 1)));
-    ws->hist = static_cast<uint32_t *>(take(4 * 256 * (size_t)ws->hist_blocks));
+    ws->hist = static_cast<uint32_t *>(take(4 * 512 * (size_t)ws->hist_blocks));
     for (int b = 0; b < 2; ++b) ws->pkey[b] = static_cast<uint32_t *>(take(4 * np));
     for (int b = 0; b < 2; ++b) ws->pval[b] = static_cast<uint32_t *>(take(4 * np));
     ws->ranges = static_cast<uint2 *>(take(sizeof(uint2) * (size_t)ws->tiles_x * ws->tiles_y));
@@ -73,7 +74,8 @@ static int check_frame(int64_t n, const GsrCamera *cam, const GsrOptions *opts, 
     if (cam->width <= 0 || cam->height <= 0 || cam->width > 65535 * GSR_TILE || cam->height > 65535 * GSR_TILE) {
         set_error("bad frame size %dx%d", cam->width, cam->height); return GSR_ERR_BAD_ARG;
     }
-    if (max_pairs < 0 || max_pairs > 0xFFFFFFF0ll) { set_error("max_pairs = %lld out of range", (long long)max_pairs); return GSR_ERR_BAD_ARG; }
+    // the sort kernels index pairs with 32-bit arithmetic, one 4096-pair tile past the last pair at most
+    if (max_pairs < 0 || max_pairs > GSR_MAX_PAIRS) { set_error("max_pairs = %lld out of range [0, %lld]", (long long)max_pairs, (long long)GSR_MAX_PAIRS); return GSR_ERR_BAD_ARG; }
     if (opts->tile_row_step < 0 || opts->tile_row_begin < 0 || opts->tile_row_begin >= std::max(opts->tile_row_step, 1)) {
         set_error("bad tile-row shard %d/%d", opts->tile_row_begin, opts->tile_row_step); return GSR_ERR_BAD_ARG;
     }
@@ -205,8 +207,7 @@ static int check_scene(const GsrScene *sc)
 }
 
 static int preprocess_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
-                           size_t workspace_bytes, const GsrDebugOut *debug, void *stream, bool keep_batch_words,
-                           bool with_color = true);
+                           size_t workspace_bytes, const GsrDebugOut *debug, void *stream, bool keep_batch_words);
 
 int gsr_preprocess(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
                    size_t workspace_bytes, const GsrDebugOut *debug, void *stream)
@@ -215,8 +216,7 @@ int gsr_preprocess(const GsrScene *scene, const GsrCamera *cam, const GsrOptions
 }
 
 static int preprocess_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
-                           size_t workspace_bytes, const GsrDebugOut *debug, void *stream, bool keep_batch_words,
-                           bool with_color)
+                           size_t workspace_bytes, const GsrDebugOut *debug, void *stream, bool keep_batch_words)
 {
     int rc = check_scene(scene);
     if (rc) return rc;
@@ -226,26 +226,10 @@ static int preprocess_impl(const GsrScene *scene, const GsrCamera *cam, const Gs
     rc = check_frame(scene->n, cam, opts, 0, workspace, workspace_bytes, &ws);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static_assert(sizeof(FrameCtrl) % 4 == 0 && offsetof(FrameCtrl, batch_overflow) % 4 == 0, "FrameCtrl is cleared by words");
-    const int reset_words = (int)((keep_batch_words ? offsetof(FrameCtrl, batch_overflow) : sizeof(FrameCtrl)) / 4);
-    return launch_preprocess(*scene, *cam, *opts, ws, debug, with_color, reset_words, s);
-}
-
-int gsr_preprocess_geometry(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
-                            size_t workspace_bytes, void *stream)
-{
-    return preprocess_impl(scene, cam, opts, workspace, workspace_bytes, nullptr, stream, false, false);
-}
-
-int gsr_preprocess_color(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
-                         size_t workspace_bytes, void *stream)
-{
-    int rc = check_scene(scene);
-    if (rc) return rc;
-    Workspace ws;
-    rc = check_frame(scene->n, cam, opts, 0, workspace, workspace_bytes, &ws);
-    if (rc) return rc;
-    return launch_color(*scene, *cam, ws, static_cast<hipStream_t>(stream));
+    static_assert(offsetof(FrameCtrl, depth_key_max) % 4 == 0 && offsetof(FrameCtrl, batch_overflow) % 4 == 0, "FrameCtrl is cleared by words");
+    // never cleared here: depth_key_max (the depth sort zeroes it itself once consumed)
+    const int reset_words = (int)((keep_batch_words ? offsetof(FrameCtrl, batch_overflow) : offsetof(FrameCtrl, depth_key_max)) / 4);
+    return launch_preprocess(*scene, *cam, *opts, ws, debug, reset_words, s);
 }
 
 int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs, void *workspace,
@@ -255,18 +239,12 @@ int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_
     int rc = check_frame(n, cam, opts, max_pairs, workspace, workspace_bytes, &ws);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    int buf = 0;
-    // depth order: 32 key bits = 4 x 8-bit passes; pass 0 drops culled gaussians and leaves V in ctrl
-    const bool packed = rect_fits_8bit(ws);
-    rc = launch_radix_sort(ws.key, ws.val, packed ? ws.rect8 : nullptr, nullptr, n, 32, true, true, &ws.ctrl->n_visible,
-                           DEPTH_SORT_ITEMS, ws, &buf, s);
+    // depth order: pass 0 drops culled gaussians and leaves V in ctrl; 3 passes on ordinary scenes (sort.hip)
+    rc = launch_depth_sort(ws, rect_fits_8bit(ws), s);
     if (rc) return rc;
-    rc = launch_binning(*cam, *opts, ws, buf, packed, s);
-    if (rc) return rc;
+    // pairs in depth order, stably sorted by tile; E in ctrl
     int pbuf = 0;
-    // tile lists: stable sort by tile id; pass 0 drops the pairs the emit kernel culled and leaves E in ctrl
-    rc = launch_radix_sort(ws.pkey, ws.pval, nullptr, &ws.ctrl->n_slots, max_pairs, tile_key_bits(ws.tiles_x * ws.tiles_y), true, false,
-                           &ws.ctrl->n_pairs, PAIR_SORT_ITEMS, ws, &pbuf, s);
+    rc = launch_binning(*opts, ws, &pbuf, s);
     if (rc) return rc;
     return launch_tile_ranges(ws, pbuf, s);
 }
@@ -278,8 +256,7 @@ int gsr_blend(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t m
     Workspace ws;
     int rc = check_frame(n, cam, opts, max_pairs, workspace, workspace_bytes, &ws);
     if (rc) return rc;
-    const int pbuf = ((tile_key_bits(ws.tiles_x * ws.tiles_y) + 7) / 8) & 1;  // ping-pong parity of the tile sort's passes
-    return launch_blend(*cam, *opts, ws, max_pairs > 0 ? pbuf : 0, out_image, out_final_T, static_cast<hipStream_t>(stream));
+    return launch_blend(*cam, *opts, ws, pair_result_buf(ws), out_image, out_final_T, static_cast<hipStream_t>(stream));
 }
 
 static int render_forward_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,
@@ -327,13 +304,13 @@ int gsr_render_batch(const GsrScene *scene, const GsrCamera *cams, int32_t n_cam
     return GSR_OK;
 }
 
-int gsr_read_stats(const void *workspace, size_t workspace_bytes, GsrStats *out, void *stream)
+int gsr_read_stats(void *workspace, size_t workspace_bytes, GsrStats *out, void *stream)
 {
     if (!workspace || !out || workspace_bytes < sizeof(FrameCtrl)) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
     static_assert(sizeof(GsrStats) == 40, "GsrStats is the head of FrameCtrl");
     hipStream_t s = static_cast<hipStream_t>(stream);
     {  // total the blend's per-workgroup counters; the kernel finds them through the offsets kept in FrameCtrl
-        const int rc = launch_blend_stats(static_cast<FrameCtrl *>(const_cast<void *>(workspace)), workspace_bytes, s);
+        const int rc = launch_blend_stats(static_cast<FrameCtrl *>(workspace), workspace_bytes, s);
         if (rc != GSR_OK) return rc;
     }
     GSR_HIP(hipMemcpyAsync(out, workspace, sizeof(GsrStats), hipMemcpyDeviceToHost, s));

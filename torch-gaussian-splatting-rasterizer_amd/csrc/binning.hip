@@ -1,27 +1,40 @@
-// binning.hip — stage 2b: (gaussian, tile) pair emission in depth order and per-tile ranges.
+// binning.hip — stage 2b: (gaussian, tile) pairs in depth order, sorted by tile, and per-tile ranges.
 //
 // No reference counterpart: the reference visits every gaussian's pixel rect sequentially
 // (rasterize.py:440-446); here each visible gaussian is expanded into the 16x16 tiles
 // (BLOCK_SIZE, rasterize.py:34) of its rect so that tiles can be composited independently.
 //
-//   count   one thread per depth-sorted gaussian: tiles of its rect that belong to this shard
-//           (tile rows begin, begin+step, ...) -> per-workgroup sums.  The rect arrives packed in the depth
-//           sort's second payload (coalesced); frames wider than 4096 px gather it by gaussian id instead.
-//   scan    one workgroup: exclusive scan of the workgroup sums; D, overflow flag, slots = min(D, max_pairs)
-//   emit    load-balanced expansion: a workgroup owns 256 consecutive gaussians and the contiguous slot range
-//           their pairs occupy; every thread takes slots j, j+256, ..., finds the owning gaussian by binary
-//           search over the workgroup's 256 offsets in LDS and writes (tile id, gaussian id) — coalesced stores,
-//           no divergence however heavy-tailed the rect sizes are (median 4 tiles, max thousands).
-//           Rects above CULL_MIN_TILES tiles are tested tile by tile against the gaussian's alpha > 1/255
-//           footprint (footprint.h): unreachable tiles (corners of oblique ellipses) get KEY_INVALID and are
-//           dropped by pass 0 of the tile sort.  Smaller rects skip the test (it needs a 32-B gather per
-//           gaussian; the blend culls per 8x8 quadrant anyway).
-//   ranges  boundaries of equal tile ids in the tile-sorted pair array -> ranges[tile] = [begin, end)
+// Pair key = (tile row << bits_x) | tile column; a pair that footprint culling rejects keeps its column and takes the
+// row `tiles_y` (one past the last), so that it still owns the slot the counting pass gave it and is dropped by the
+// sort pass over the row bits.  Stable sort by column, then by row => per-tile lists in depth order.
+//
+// FUSED PATH (frames up to 4096 px, i.e. <= 256 tile columns and < 256 tile rows): pairs are never written in emission
+// order.  The first radix pass of the tile sort (digit = tile column) is folded into pair generation:
+//   pair_hist      one workgroup per block of PAIR_BLOCK depth-sorted gaussians (rects arrive packed, coalesced, as the
+//                  depth sort's second payload): for every gaussian, +rows into every column of its rect (LDS atomics)
+//                  -> hist[column][block].  This IS the pass-0 histogram; no pair is generated for it.
+//   rowscan        (sort.hip) exclusive scan of every column's row, column totals -> digit_tot
+//   pair_scatter0  same blocks: the block's pairs are generated 4096 at a time in emission order (slot -> owning gaussian
+//                  by binary search over the block's offsets in LDS, -> row/column inside its rect), ranked and reordered
+//                  by column with the machinery of the radix scatter (radix.h) and written straight to their
+//                  column-sorted positions.  A block holding a frame-covering gaussian simply takes more rounds.
+//                  Rects above CULL_MIN_TILES tiles are tested tile by tile against the gaussian's alpha > 1/255
+//                  footprint (footprint.h); smaller rects skip the test (the blend culls per 8x8 quadrant anyway).
+//                  Workgroup 0 also totals D = sum of the column totals: overflow flag, slots = min(D, max_pairs).
+//   then one ordinary radix pass over the row bits (sort.hip) and
+//   ranges         boundaries of equal keys in the sorted pair array -> ranges[tile] = [begin, end)
+// Against emit + a separate pass 0 this removes the emit kernel, the pass-0 histogram kernel, the block-offset scan, and
+// one write + two reads of the pair arrays.
+//
+// LEGACY PATH (wider frames; GSR_LEGACY_BINNING=1 forces it for A/B timing): count -> scan -> emit in emission order,
+// then the generic sort over all key bits.
 // Roofline: HBM.  Bytes: 8 B per sorted gaussian (id + rect) + 8 B per pair written; ranges reads 4 B per pair.
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include "gsr_internal.h"
 #include "footprint.h"
+#include "radix.h"
 
 namespace gsr {
 
@@ -60,6 +73,188 @@ __device__ __forceinline__ ushort4 unpack_rect8(uint32_t r)
                         (unsigned short)((r >> 24) + 1u));
 }
 
+// k-th tile of a rect of width w in row-major order -> (row, col).  k < 2^24: float division is exact up to the fix-up.
+__device__ __forceinline__ void row_col(uint32_t k, uint32_t w, uint32_t *row, uint32_t *col)
+{
+    uint32_t r = (uint32_t)((float)k / (float)w);
+    if (r * w > k) --r;
+    else if ((r + 1) * w <= k) ++r;
+    *row = r;
+    *col = k - r * w;
+}
+
+// ============================================ fused path =====================================================
+
+__global__ __launch_bounds__(EMIT_THREADS) void pair_hist_kernel(const uint32_t *__restrict__ r8_a, const uint32_t *__restrict__ r8_b,
+                                                                 const FrameCtrl *ctrl, Shard sh, uint32_t *__restrict__ hist,
+                                                                 int hist_blocks, uint2 *__restrict__ ranges, int n_tiles,
+                                                                 uint32_t grid_threads, uint32_t draw_limit)
+{
+    __shared__ uint32_t colh[256];
+    const int tid = threadIdx.x;
+    for (uint32_t t = blockIdx.x * EMIT_THREADS + tid; t < (uint32_t)n_tiles; t += grid_threads) ranges[t] = make_uint2(0u, 0u);  // rebuilt every frame
+    const uint32_t n = ctrl->n_visible;
+    const uint32_t gbase = blockIdx.x * (uint32_t)PAIR_BLOCK;
+    if (gbase >= n) return;  // uniform; the rowscan stops at the live blocks too
+    const uint32_t *__restrict__ r8 = (ctrl->sort_passes & 1u) ? r8_b : r8_a;  // where the depth sort left its result
+    colh[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PAIR_BLOCK / EMIT_THREADS; ++k) {
+        const uint32_t r = gbase + k * EMIT_THREADS + tid;  // rank in the draw order
+        if (r < n && r < draw_limit) {
+            const ushort4 rc = unpack_rect8(r8[r]);
+            int first, rows;
+            shard_rows(rc.y, rc.w, sh, &first, &rows);
+            if (rows > 0)
+                for (int tx = rc.x; tx < rc.z; ++tx) atomicAdd(&colh[tx], (uint32_t)rows);
+        }
+    }
+    __syncthreads();
+    hist[(size_t)tid * hist_blocks + blockIdx.x] = colh[tid];
+}
+
+__global__ __launch_bounds__(EMIT_THREADS) void pair_scatter0_kernel(const uint32_t *__restrict__ id_a, const uint32_t *__restrict__ id_b,
+                                                                     const uint32_t *__restrict__ r8_a, const uint32_t *__restrict__ r8_b,
+                                                                     FrameCtrl *ctrl, Shard sh, int bits_x, int tiles_y,
+                                                                     const GaussRec *__restrict__ rec, const uint32_t *__restrict__ hist,
+                                                                     int hist_blocks, uint32_t max_pairs, uint32_t *__restrict__ pkey,
+                                                                     uint32_t *__restrict__ pval, uint32_t draw_limit)
+{
+    using Smem = RadixTileSmem<256, PAIR_SORT_ITEMS, false>;
+    constexpr int ITEMS = PAIR_SORT_ITEMS, TILE = Smem::TILE, PER = PAIR_BLOCK / EMIT_THREADS;
+    __shared__ Smem sm;
+    __shared__ uint32_t s_off[PAIR_BLOCK + 1];  // exclusive pair offset of each gaussian inside the block
+    __shared__ uint32_t s_id[PAIR_BLOCK];
+    __shared__ uint32_t s_r8[PAIR_BLOCK];
+    __shared__ unsigned long long s_base[256];  // next global position of column d for this block (64-bit: D may pass 2^32)
+    __shared__ unsigned long long s_wsum[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n = ctrl->n_visible;
+    const uint32_t gbase = blockIdx.x * (uint32_t)PAIR_BLOCK;
+    if (gbase >= n && blockIdx.x != 0) return;  // uniform.  Workgroup 0 always runs: it publishes D
+    const bool odd = (ctrl->sort_passes & 1u) != 0;
+    const uint32_t *__restrict__ ids = odd ? id_b : id_a;
+    const uint32_t *__restrict__ r8 = odd ? r8_b : r8_a;
+
+    // ---- this block's gaussians (thread t owns PER consecutive ones), their pair counts and offsets -------------
+    uint32_t cnt[PER], mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tid * PER + k;
+        const uint32_t r = gbase + i;
+        uint32_t g = 0, packed = 1u;  // packed {x0 = 1, x1 - 1 = 0}: zero width
+        cnt[k] = 0;
+        if (r < n && r < draw_limit) {
+            g = ids[r];
+            packed = r8[r];
+            int first;
+            cnt[k] = tiles_of(unpack_rect8(packed), sh, &first);
+        }
+        s_id[i] = g;
+        s_r8[i] = packed;
+        mine += cnt[k];
+    }
+    uint32_t total;
+    {
+        uint32_t ex = block_excl_scan_256(mine, sm.scratch, &total);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { s_off[tid * PER + k] = ex; ex += cnt[k]; }
+        if (tid == 0) s_off[PAIR_BLOCK] = total;
+    }
+    // ---- global start of every column for this block: scan of the column totals (64-bit) + the scanned histogram -----
+    {
+        const unsigned long long tot = ctrl->digit_tot[tid];
+        unsigned long long incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        unsigned long long wbase = 0, D = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const unsigned long long sw = s_wsum[w];
+            if (w < wave) wbase += sw;
+            D += sw;
+        }
+        s_base[tid] = wbase + (incl - tot) + (gbase < n ? hist[(size_t)tid * hist_blocks + blockIdx.x] : 0u);
+        if (blockIdx.x == 0 && tid == 0) {
+            const uint32_t Dc = D > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)D;
+            // batch_overflow / batch_need survive the per-frame clear inside gsr_render_batch: an overflow in any view of
+            // a batch stays visible in the counters of the last one, together with the largest D of the batch
+            if (D > (unsigned long long)max_pairs) { ctrl->batch_overflow = 1u; ctrl->batch_need = max(ctrl->batch_need, Dc); }
+            ctrl->overflow = ctrl->batch_overflow;
+            ctrl->n_pairs_bbox = ctrl->batch_overflow ? max(ctrl->batch_need, Dc) : Dc;
+            ctrl->n_slots = D > (unsigned long long)max_pairs ? max_pairs : (uint32_t)D;
+        }
+    }
+    if (gbase >= n) return;  // workgroup 0 of an empty frame
+    const uint32_t maskx = (1u << bits_x) - 1u;
+    const uint32_t culled_row = (uint32_t)tiles_y << bits_x;
+
+    // ---- rounds of TILE pairs in emission order ------------------------------------------------------------------
+    for (uint32_t round = 0; round < total; round += TILE) {
+        __syncthreads();  // s_off / s_base ready (first round); previous round's LDS tile fully written out (later rounds)
+        radix_clear(sm);
+        __syncthreads();
+        uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+        const uint32_t dummy[1] = {0u};
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const uint32_t j = round + wave * (64 * ITEMS) + r * 64 + lane;
+            key[r] = KEY_INVALID;
+            val[r] = 0u;
+            if (j < total) {
+                // owner = last gaussian whose offset is <= j (zero-count gaussians share an offset with their successor)
+                int lo = 0;
+#pragma unroll
+                for (int step = 512; step >= 1; step >>= 1)
+                    if (lo + step < PAIR_BLOCK && s_off[lo + step] <= j) lo += step;
+                const uint32_t k = j - s_off[lo];
+                const ushort4 rc = unpack_rect8(s_r8[lo]);
+                uint32_t row, col;
+                row_col(k, (uint32_t)(rc.z - rc.x), &row, &col);
+                int first, rows;
+                shard_rows(rc.y, rc.w, sh, &first, &rows);
+                const int ty = first + (int)row * sh.step, tx = (int)rc.x + (int)col;
+                const uint32_t g = s_id[lo];
+                bool hit = true;
+                if ((uint32_t)rows * (uint32_t)(rc.z - rc.x) > CULL_MIN_TILES)
+                    hit = footprint_hits_rect(rec[g].q0, rec[g].q1, (float)(tx * 16), (float)(tx * 16 + 15), (float)(ty * 16),
+                                              (float)(ty * 16 + 15));
+                key[r] = (hit ? (uint32_t)ty << bits_x : culled_row) | (uint32_t)tx;
+                val[r] = g;
+            }
+        }
+        auto dig = [&](int r) -> uint32_t { return key[r] == KEY_INVALID ? RADIX_NO_DIGIT : key[r] & maskx; };
+        radix_rank(sm, dig, rank);
+        __syncthreads();
+        uint32_t dcnt[1];
+        radix_tile_layout(sm, dcnt);
+        __syncthreads();
+        radix_reorder(sm, dig, rank, key, val, dummy);
+        __syncthreads();
+        const uint32_t nvalid = sm.n_valid;
+        for (uint32_t i = tid; i < nvalid; i += EMIT_THREADS) {
+            const uint32_t kk = sm.skey[i];
+            const uint32_t d = kk & maskx;
+            const unsigned long long gpos = s_base[d] + (i - sm.tile_start[d]);
+            if (gpos < (unsigned long long)max_pairs) {
+                pkey[gpos] = kk;
+                pval[gpos] = sm.sval[i];
+            }
+        }
+        __syncthreads();
+        s_base[tid] += dcnt[0];  // thread t owns column t
+    }
+}
+
+// ============================================ legacy path ====================================================
+
 template <bool PACKED>
 __device__ __forceinline__ ushort4 rect_of(uint32_t r, const uint32_t *sorted_ids, const uint32_t *sorted_rect8, const ushort4 *rect)
 {
@@ -67,14 +262,16 @@ __device__ __forceinline__ ushort4 rect_of(uint32_t r, const uint32_t *sorted_id
 }
 
 template <bool PACKED>
-__global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t *__restrict__ sorted_ids,
-                                                                  const uint32_t *__restrict__ sorted_rect8, const FrameCtrl *ctrl,
-                                                                  const ushort4 *__restrict__ rect, Shard sh,
+__global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t *__restrict__ id_a, const uint32_t *__restrict__ id_b,
+                                                                  const uint32_t *__restrict__ r8_a, const uint32_t *__restrict__ r8_b,
+                                                                  const FrameCtrl *ctrl, const ushort4 *__restrict__ rect, Shard sh,
                                                                   uint32_t *__restrict__ blk_sum, uint2 *__restrict__ ranges,
                                                                   int n_tiles, uint32_t draw_limit)
 {
     __shared__ uint32_t scratch[8];
     const uint32_t n = ctrl->n_visible;
+    const bool odd = (ctrl->sort_passes & 1u) != 0;
+    const uint32_t *sorted_ids = odd ? id_b : id_a, *sorted_rect8 = odd ? r8_b : r8_a;
     const uint32_t r = blockIdx.x * EMIT_THREADS + threadIdx.x;
     if (r < (uint32_t)n_tiles) ranges[r] = make_uint2(0u, 0u);  // tile ranges are rebuilt every frame
     uint32_t cnt = 0;
@@ -149,8 +346,6 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(uint32_t *__restrict__ 
     if (tid == 0) {
         const unsigned long long D = grand;
         const uint32_t Dc = D > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)D;
-        // batch_overflow / batch_need survive the per-frame clear inside gsr_render_batch: an overflow in any view of
-        // a batch stays visible in the counters of the last one, together with the largest D of the batch
         if (D > (unsigned long long)max_pairs) { ctrl->batch_overflow = 1u; ctrl->batch_need = max(ctrl->batch_need, Dc); }
         ctrl->overflow = ctrl->batch_overflow;
         ctrl->n_pairs_bbox = ctrl->batch_overflow ? max(ctrl->batch_need, Dc) : Dc;
@@ -158,11 +353,14 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(uint32_t *__restrict__ 
     }
 }
 
+// Load-balanced expansion in emission order: a workgroup owns 256 consecutive gaussians and the contiguous slot range
+// their pairs occupy; every thread takes slots j, j+256, ..., finds the owning gaussian by binary search over the
+// workgroup's 256 offsets in LDS and writes (tile key, gaussian id) — coalesced stores however heavy-tailed the rects are.
 template <bool PACKED>
-__global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t *__restrict__ sorted_ids,
-                                                                 const uint32_t *__restrict__ sorted_rect8, const FrameCtrl *ctrl,
-                                                                 const ushort4 *__restrict__ rect, Shard sh, int tiles_x,
-                                                                 const GaussRec *__restrict__ rec,
+__global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t *__restrict__ id_a, const uint32_t *__restrict__ id_b,
+                                                                 const uint32_t *__restrict__ r8_a, const uint32_t *__restrict__ r8_b,
+                                                                 const FrameCtrl *ctrl, const ushort4 *__restrict__ rect, Shard sh,
+                                                                 int bits_x, int tiles_y, const GaussRec *__restrict__ rec,
                                                                  const uint32_t *__restrict__ blk_off, uint32_t max_pairs,
                                                                  uint32_t *__restrict__ pkey, uint32_t *__restrict__ pval,
                                                                  uint32_t draw_limit)
@@ -175,6 +373,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
     __shared__ float4 s_q0[EMIT_THREADS];
     __shared__ float4 s_q1[EMIT_THREADS];
     const uint32_t n = ctrl->n_visible;
+    const bool odd = (ctrl->sort_passes & 1u) != 0;
+    const uint32_t *sorted_ids = odd ? id_b : id_a, *sorted_rect8 = odd ? r8_b : r8_a;
     const int tid = threadIdx.x;
     const uint32_t r = blockIdx.x * EMIT_THREADS + tid;
     if (blockIdx.x * EMIT_THREADS >= n) return;  // uniform
@@ -195,7 +395,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
     s_first[tid] = test ? -1 - first : first;
     __syncthreads();
 
-    const uint32_t base = blk_off[blockIdx.x];
+    const unsigned long long base = blk_off[blockIdx.x];  // saturated at 2^32 - 1 by the scan: then nothing below is written
+    const uint32_t culled_row = (uint32_t)tiles_y << bits_x;
     for (uint32_t j = tid; j < total; j += EMIT_THREADS) {
         // owner = last gaussian whose offset is <= j (zero-count gaussians share an offset with their successor)
         int lo = 0;
@@ -204,30 +405,31 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
             if (s_off[lo + step] <= j) lo += step;
         const uint32_t k = j - s_off[lo];
         const uint32_t geo = s_geo[lo];
-        const uint32_t w = geo >> 16;
-        uint32_t row = (uint32_t)((float)k / (float)w);  // k < 2^24: exact up to the rounding fixed below
-        if (row * w > k) --row;
-        else if ((row + 1) * w <= k) ++row;
-        const uint32_t col = k - row * w;
+        uint32_t row, col;
+        row_col(k, geo >> 16, &row, &col);
         const int fr = s_first[lo];
         const bool tested = fr < 0;
         const int ty = (tested ? -1 - fr : fr) + (int)row * sh.step, tx = (int)(geo & 0xFFFFu) + (int)col;
-        const uint32_t o = base + j;
-        if (o < max_pairs) {
+        const unsigned long long o = base + j;
+        if (o < (unsigned long long)max_pairs) {
             const bool hit = !tested || footprint_hits_rect(s_q0[lo], s_q1[lo], (float)(tx * 16), (float)(tx * 16 + 15),
                                                             (float)(ty * 16), (float)(ty * 16 + 15));
-            pkey[o] = hit ? (uint32_t)ty * (uint32_t)tiles_x + (uint32_t)tx : KEY_INVALID;
+            pkey[o] = (hit ? (uint32_t)ty << bits_x : culled_row) | (uint32_t)tx;
             pval[o] = s_id[lo];
         }
     }
 }
 
+// ============================================ tile ranges =====================================================
+
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t *__restrict__ pkey, const FrameCtrl *ctrl,
-                                                          uint2 *__restrict__ ranges, int n_tiles, uint32_t stride)
+                                                          uint2 *__restrict__ ranges, int bits_x, int tiles_x, int n_tiles,
+                                                          uint32_t stride)
 {
     // four keys per thread from one 16-B load; only the two keys flanking the group are read a second time.
     // stride = threads in the grid, passed in: gridDim / blockDim would pull in the 256-B hidden kernarg block
     const uint32_t n = ctrl->n_pairs;
+    const uint32_t maskx = (1u << bits_x) - 1u;
     for (uint32_t t = blockIdx.x * 256u + threadIdx.x; 4ull * t < n; t += stride) {
         const uint32_t i = 4u * t;
         uint32_t k[6];  // k[0] = key before the group, k[1..4] = the group, k[5] = key after it
@@ -238,57 +440,87 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t *__rest
 #pragma unroll
             for (int j = 0; j < 4; ++j) k[1 + j] = i + j < n ? pkey[i + j] : KEY_INVALID;
         }
-        k[0] = i > 0 ? pkey[i - 1] : KEY_INVALID;            // KEY_INVALID never survives pass 0: always a boundary
+        k[0] = i > 0 ? pkey[i - 1] : KEY_INVALID;            // KEY_INVALID is no pair key: always a boundary
         k[5] = i + 4 < n ? pkey[i + 4] : KEY_INVALID;
 #pragma unroll
         for (int j = 1; j <= 4; ++j) {
             const uint32_t idx = i + (uint32_t)(j - 1);
             const uint32_t key = k[j];
-            if (idx >= n || key >= (uint32_t)n_tiles) continue;  // the second test cannot fail; it keeps a corrupt key in bounds
-            if (k[j - 1] != key) ranges[key].x = idx;
-            if (idx + 1 == n || k[j + 1] != key) ranges[key].y = idx + 1;
+            const uint32_t tx = key & maskx, tile = (key >> bits_x) * (uint32_t)tiles_x + tx;
+            if (idx >= n || tx >= (uint32_t)tiles_x || tile >= (uint32_t)n_tiles) continue;  // the last two cannot fail; they keep a corrupt key in bounds
+            if (k[j - 1] != key) ranges[tile].x = idx;
+            if (idx + 1 == n || k[j + 1] != key) ranges[tile].y = idx + 1;
         }
     }
 }
 
-int tile_key_bits(int tiles)
+static int ceil_log2(int v)
 {
-    int bits = 1;
-    while ((1 << bits) < tiles) ++bits;
+    int bits = 0;
+    while ((1 << bits) < v) ++bits;
     return bits;
 }
 
-int launch_binning(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int sorted_buf, bool packed_rect,
-                   hipStream_t s)
+TileKeying tile_keying(const Workspace &ws)
 {
-    (void)cam;
+    TileKeying k;
+    k.bits_x = std::max(1, ceil_log2(ws.tiles_x));
+    k.bits_y = std::max(1, ceil_log2(ws.tiles_y + 1));  // one spare row value marks culled pairs
+    k.drop_from = (uint32_t)ws.tiles_y << k.bits_x;
+    k.fused = rect_fits_8bit(ws) && k.bits_x <= 8 && k.bits_y <= 8;
+    if (k.fused) {
+        const char *e = std::getenv("GSR_LEGACY_BINNING");
+        if (e && e[0] == '1') k.fused = false;
+    }
+    return k;
+}
+
+// Pairs of the depth-sorted gaussians, sorted by tile.  *pair_buf: which of pkey[]/pval[] holds the result.
+int pair_result_buf(const Workspace &ws)
+{
+    if (ws.n <= 0 || ws.max_pairs <= 0) return 0;
+    const TileKeying tk = tile_keying(ws);
+    if (tk.fused) return 1 ^ (((tk.bits_y + 7) / 8) & 1);  // generated into buffer 1, then the passes over the row bits
+    return ((tk.bits_x + tk.bits_y + 7) / 8) & 1;
+}
+
+int launch_binning(const GsrOptions &opts, const Workspace &ws, int *pair_buf, hipStream_t s)
+{
+    *pair_buf = 0;
     if (ws.n <= 0) return GSR_OK;
+    const bool packed_rect = rect_fits_8bit(ws);
     const Shard sh = {opts.tile_row_begin, opts.tile_row_step < 1 ? 1 : opts.tile_row_step};
     const int n_tiles = ws.tiles_x * ws.tiles_y;
+    const TileKeying tk = tile_keying(ws);
+    const uint32_t cap = (uint32_t)ws.max_pairs;
+    const uint32_t limit = opts.draw_limit > 0 ? (uint32_t)opts.draw_limit : 0xFFFFFFFFu;
+    if (tk.fused) {
+        const int nblk = (int)((ws.n + PAIR_BLOCK - 1) / PAIR_BLOCK);
+        if (nblk > ws.hist_blocks) { set_error("binning: %d blocks exceed the histogram stride %d", nblk, ws.hist_blocks); return GSR_ERR_WORKSPACE; }
+        hipLaunchKernelGGL(pair_hist_kernel, dim3(nblk), dim3(EMIT_THREADS), 0, s, ws.rect8[0], ws.rect8[1], ws.ctrl, sh, ws.hist,
+                           ws.hist_blocks, ws.ranges, n_tiles, (uint32_t)nblk * EMIT_THREADS, limit);
+        launch_rowscan_blocks(ws, 256, PAIR_BLOCK, &ws.ctrl->n_visible, ws.n, s);  // all 256 rows: the scatter scans digit_tot[0..256)
+        hipLaunchKernelGGL(pair_scatter0_kernel, dim3(nblk), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1],
+                           ws.ctrl, sh, tk.bits_x, ws.tiles_y, ws.rec, ws.hist, ws.hist_blocks, cap, ws.pkey[1], ws.pval[1], limit);
+        GSR_HIP(hipGetLastError());
+        // second pass: the row bits; drops the culled pairs (row == tiles_y) and leaves E in ctrl
+        return launch_pair_sort(ws, 1, &ws.ctrl->n_slots, tk.bits_x, tk.bits_x + tk.bits_y, tk.drop_from, &ws.ctrl->n_pairs, pair_buf, s);
+    }
     // the count kernel also zeroes ranges[]: make sure its grid covers them
     const int nblk = (int)((std::max<int64_t>(ws.n, n_tiles) + EMIT_THREADS - 1) / EMIT_THREADS);
     const int nblk_n = (int)((ws.n + EMIT_THREADS - 1) / EMIT_THREADS);
-    const uint32_t *ids = ws.val[sorted_buf];
-    const uint32_t *r8 = ws.rect8[sorted_buf];
-    const uint32_t cap = (uint32_t)ws.max_pairs;
-    const uint32_t limit = opts.draw_limit > 0 ? (uint32_t)opts.draw_limit : 0xFFFFFFFFu;
-    if (packed_rect) {
-        hipLaunchKernelGGL(pair_count_kernel<true>, dim3(nblk), dim3(EMIT_THREADS), 0, s, ids, r8, ws.ctrl, ws.rect, sh, ws.blk_sum,
-                           ws.ranges, n_tiles, limit);
-    } else {
-        hipLaunchKernelGGL(pair_count_kernel<false>, dim3(nblk), dim3(EMIT_THREADS), 0, s, ids, r8, ws.ctrl, ws.rect, sh, ws.blk_sum,
-                           ws.ranges, n_tiles, limit);
-    }
+#define GSR_COUNT(P) hipLaunchKernelGGL(pair_count_kernel<P>, dim3(nblk), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
+                                        ws.ctrl, ws.rect, sh, ws.blk_sum, ws.ranges, n_tiles, limit)
+#define GSR_EMIT(P) hipLaunchKernelGGL(pair_emit_kernel<P>, dim3(nblk_n), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
+                                       ws.ctrl, ws.rect, sh, tk.bits_x, ws.tiles_y, ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0], limit)
+    if (packed_rect) GSR_COUNT(true); else GSR_COUNT(false);
     hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, ws.blk_sum, nblk_n, ws.ctrl, cap);
-    if (packed_rect) {
-        hipLaunchKernelGGL(pair_emit_kernel<true>, dim3(nblk_n), dim3(EMIT_THREADS), 0, s, ids, r8, ws.ctrl, ws.rect, sh, ws.tiles_x,
-                           ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0], limit);
-    } else {
-        hipLaunchKernelGGL(pair_emit_kernel<false>, dim3(nblk_n), dim3(EMIT_THREADS), 0, s, ids, r8, ws.ctrl, ws.rect, sh, ws.tiles_x,
-                           ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0], limit);
-    }
+    if (packed_rect) GSR_EMIT(true); else GSR_EMIT(false);
+#undef GSR_COUNT
+#undef GSR_EMIT
     GSR_HIP(hipGetLastError());
-    return GSR_OK;
+    // tile lists: stable sort by tile key; the first pass drops the pairs the emit kernel culled and leaves E in ctrl
+    return launch_pair_sort(ws, 0, &ws.ctrl->n_slots, 0, tk.bits_x + tk.bits_y, tk.drop_from, &ws.ctrl->n_pairs, pair_buf, s);
 }
 
 int launch_tile_ranges(const Workspace &ws, int pair_buf, hipStream_t s)
@@ -299,9 +531,10 @@ int launch_tile_ranges(const Workspace &ws, int pair_buf, hipStream_t s)
         return GSR_OK;
     }
     if (ws.max_pairs <= 0) return GSR_OK;
+    const TileKeying tk = tile_keying(ws);
     const int grid = (int)std::min<int64_t>((ws.max_pairs + 1023) / 1024, 8192);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(grid), dim3(256), 0, s, ws.pkey[pair_buf], ws.ctrl, ws.ranges, n_tiles,
-                       (uint32_t)grid * 256u);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(grid), dim3(256), 0, s, ws.pkey[pair_buf], ws.ctrl, ws.ranges, tk.bits_x, ws.tiles_x,
+                       n_tiles, (uint32_t)grid * 256u);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

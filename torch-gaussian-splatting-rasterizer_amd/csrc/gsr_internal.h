@@ -21,11 +21,19 @@ struct FrameCtrl {
     uint32_t n_slots;       // min(D, max_pairs): pair slots written by the emit kernel
     unsigned long long wave_entries;  // (quadrant, entry) pairs evaluated by the blend   } totals of blend_stats[], filled in
     unsigned long long fetched_entries;  // list entries staged by the blend              } by gsr_read_stats
-    uint32_t digit_tot[256]; // per-digit totals of the radix pass in flight
+    uint32_t digit_tot[512]; // per-digit totals of the radix pass in flight
     uint32_t stats_off;      // byte offset of blend_stats[] from this struct, and the number of launch slots the last
     uint32_t stats_slots;    // blend filled (tile_order_kernel writes both; 0 = no blend since the frame was reset)
-    uint32_t batch_overflow; // sticky across the views of gsr_render_batch (not cleared per frame)
+    uint32_t sort_passes;    // depth-sort plan of this frame (sort.hip): passes that run (1..4) — the sorted ids end up in
+    uint32_t sort_key_bits;  //   val[sort_passes & 1]; significant bits of key - bits(0.2f); digit width of the passes
+    uint32_t sort_bits_rest; //   after the first.  Written by the pass-0 rowscan.
+    uint32_t _pad0;
+    // ---- everything below survives the per-frame clear ----
+    uint32_t batch_overflow; // sticky across the views of gsr_render_batch
     uint32_t batch_need;     // largest D seen in the batch
+    uint32_t depth_key_max;  // running maximum of the valid depth keys (pass-0 histogram); consumed and zeroed by the pass-0
+                             // rowscan.  Garbage in a fresh workspace only makes the first frame sort over more bits.
+    uint32_t _pad1;
 };
 constexpr int BLEND_STAT_WORDS = 8;  // per launch slot: [0..3] evaluated entries of waves 0..3, [4] staged entries
 
@@ -40,21 +48,25 @@ struct alignas(16) GaussRec {
 constexpr int SORT_THREADS = 256;
 constexpr int DEPTH_SORT_ITEMS = 16;  // keys per thread per pass (2048-key tiles measured slower: fixed per-workgroup costs dominate)
 constexpr int PAIR_SORT_ITEMS = 16;
-constexpr int EMIT_THREADS = 256;                     // gaussians per workgroup in count/emit
+constexpr int EMIT_THREADS = 256;                     // threads per workgroup in the binning kernels
+#ifndef GSR_PAIR_BLOCK
+#define GSR_PAIR_BLOCK 768
+#endif
+constexpr int PAIR_BLOCK = GSR_PAIR_BLOCK;            // gaussians per workgroup of the fused binning path: ~3.6 k pairs on a full-HD frame = one round of 4096
+static_assert(PAIR_BLOCK % EMIT_THREADS == 0 && PAIR_BLOCK <= 1024, "whole gaussians per thread; the owner search takes 10 steps");
 constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
 
 struct Workspace {
     FrameCtrl *ctrl;
     GaussRec *rec;        // [n]
     ushort4 *rect;        // [n]   tile rect {tx0, ty0, tx1, ty1} (exclusive upper), after footprint refinement
-    unsigned char *vis;   // [n]   1 = kept by the geometry pass (only written when stage 1 is split)
     uint32_t *rect8[2];   // [n]   the same rect packed x0 | y0<<8 | (x1-1)<<16 | (y1-1)<<24; rides through the depth
                           //       sort as a second payload when the tile grid fits 8 bits (frames up to 4096 px)
     uint32_t *key[2];     // [n]   depth keys (ping-pong)
     uint32_t *val[2];     // [n]   gaussian ids (ping-pong)
     uint32_t *pair_off;   // [n]   exclusive pair offsets in depth order
     uint32_t *blk_sum;    // [ceil(n/EMIT_THREADS)+1]
-    uint32_t *hist;       // [256 * hist_blocks]
+    uint32_t *hist;       // [512 * hist_blocks] digit-major: hist[digit][block]
     uint32_t *pkey[2];    // [max_pairs] tile ids
     uint32_t *pval[2];    // [max_pairs] gaussian ids
     uint2 *ranges;        // [tiles]
@@ -82,8 +94,7 @@ int hip_fail(hipError_t e, const char *what);
 
 // ---- kernels' host launchers (each returns GSR_OK / GSR_ERR_HIP) --------------------------------
 int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws,
-                      const GsrDebugOut *dbg, bool with_color, int ctrl_reset_words, hipStream_t s);
-int launch_color(const GsrScene &scene, const GsrCamera &cam, const Workspace &ws, hipStream_t s);
+                      const GsrDebugOut *dbg, int ctrl_reset_words, hipStream_t s);
 int launch_sh_to_rgb(int64_t n, const float *means, const float *sh, const float cc[3], int degree, float *rgb, hipStream_t s);
 int launch_cov3d(int64_t n, const float *log_scales, const float *quats, float *out, hipStream_t s);
 int launch_project(int64_t n, const float *means, const float w2c[16], float *out, hipStream_t s);
@@ -93,25 +104,30 @@ int launch_bbox(int64_t n, const float *screen_means, const float *cov2d, float 
 int launch_rasterize_gaussian(int64_t g, const int64_t *bboxes, float *screen, const float *screen_means, const float *sigmas,
                               const float *rgb, float *opacity_buffer, const float *opacity, int W, int H, hipStream_t s);
 
-// LSD radix sort of (key,val) u32 pairs, 8 bits per pass over bits [0, 8*passes).
-// n_dev: device pointer to the element count (may be nullptr -> n_bound is the count).
-// drop_invalid_first: pass 0 drops keys == KEY_INVALID and stores the survivor count to n_out (device).
-// On return *result_buf (0/1) tells which of key[]/val[] holds the sorted data.
-// val2 (may be nullptr): a second u32 payload moved along with val.  items_per_thread: 8 or 16.
-int launch_radix_sort(uint32_t *const key[2], uint32_t *const val[2], uint32_t *const val2[2], const uint32_t *n_dev,
-                      int64_t n_bound, int key_bits, bool drop_invalid_first, bool index_values,
-                      uint32_t *n_out, int items_per_thread, const Workspace &ws, int *result_buf, hipStream_t s);
+// Depth order (sort.hip): stable LSD radix sort of the depth keys; leaves V in FrameCtrl.n_visible and the sorted ids (+ packed
+// rects) in val[p] / rect8[p], p = FrameCtrl.sort_passes & 1 (decided on the device from the frame's key range).
+int launch_depth_sort(const Workspace &ws, bool packed_rect, hipStream_t s);
+// Stable radix sort of the pair arrays over key bits [first_bit, key_bits); the first pass drops keys >= drop_from and leaves the
+// survivor count in *n_out.  in_buf / *result_buf: which of pkey[]/pval[] holds input / output.
+int launch_pair_sort(const Workspace &ws, int in_buf, const uint32_t *n_dev, int first_bit, int key_bits, uint32_t drop_from,
+                     uint32_t *n_out, int *result_buf, hipStream_t s);
+// Exclusive scan of hist rows [0, rows) over the live blocks (blocks of `block` elements, element count *n_dev) -> digit_tot.
+void launch_rowscan_blocks(const Workspace &ws, int rows, int block, const uint32_t *n_dev, int64_t n_bound, hipStream_t s);
 
-int launch_binning(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int sorted_buf, bool packed_rect,
-                   hipStream_t s);
+// Pair keys: (tile row << bits_x) | tile column; culled pairs carry the row `tiles_y` and are dropped from drop_from on.
+struct TileKeying {
+    int bits_x, bits_y;
+    uint32_t drop_from;
+    bool fused;  // first tile-sort pass fused with pair generation (binning.hip)
+};
+TileKeying tile_keying(const Workspace &ws);
 inline bool rect_fits_8bit(const Workspace &ws) { return ws.tiles_x <= 256 && ws.tiles_y <= 256; }
+int launch_binning(const GsrOptions &opts, const Workspace &ws, int *pair_buf, hipStream_t s);
+int pair_result_buf(const Workspace &ws);  // which pair buffer launch_binning leaves the tile-sorted pairs in
 int launch_tile_ranges(const Workspace &ws, int pair_buf, hipStream_t s);
 int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int pair_buf, void *out_image,
                  float *out_T, hipStream_t s);
 int launch_blend_stats(FrameCtrl *ctrl, size_t workspace_bytes, hipStream_t s);
-
-// which pair buffer holds the tile-sorted pairs, given the tile count (passes parity)
-int tile_key_bits(int tiles);
 
 // ---- small device helpers -----------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)

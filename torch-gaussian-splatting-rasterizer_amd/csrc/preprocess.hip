@@ -8,6 +8,7 @@
 // Roofline: HBM.  Algorithmic bytes per gaussian: 236 read (xyz 12, scale 12, rot 16, opacity 4,
 // SH 192) + 52..64 written per visible gaussian.  Culled / off-screen gaussians
 // leave before the SH read.
+#include <cmath>
 #include <cstring>
 #include <algorithm>
 #include "gsr_internal.h"
@@ -20,11 +21,12 @@ struct Cam {
     float F[16];
     float cc[3];
     float fx, fy, limx, limy;
+    float w_sigma2;  // largest eigenvalue of A^T A, A = w2c[:3,:3] (1 for a unit qvec), padded: bounds |J A| in the shard early-out
     int W, H;
 };
 
-template <bool DEBUG, bool SH16, bool WITH_COLOR>
-__global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, unsigned char *__restrict__ vis, GaussRec *__restrict__ rec,
+template <bool DEBUG, bool SH16>
+__global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, GaussRec *__restrict__ rec,
                                                          ushort4 *__restrict__ rect, uint32_t *__restrict__ rect8, uint32_t *__restrict__ depth_key,
                                                          GsrDebugOut dbg,
                                                          uint32_t *__restrict__ ctrl_words, int ctrl_reset_words, int packed_rect)
@@ -53,8 +55,37 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
     const float p_w = 1.0f / (pt[3] + 0.0000001f);
     const float ndc_x = pt[0] * p_w, ndc_y = pt[1] * p_w;
 
-    // cov3D, :357
+    // NDC -> pixel, :391
+    const float Wf = (float)cam.W, Hf = (float)cam.H;
+    const float mx = ((ndc_x + 1.0f) * Wf - 1.0f) / 2.0f, my = ((ndc_y + 1.0f) * Hf - 1.0f) / 2.0f;
+
     const float ls[3] = {sc.log_scales[3 * i], sc.log_scales[3 * i + 1], sc.log_scales[3 * i + 2]};
+    // ---- multi-GPU shard early-out (tile rows row_begin, row_begin + row_step, ...) ---------------------------
+    // Before the quaternion load and the covariance math: a bound on the reference's radius (:179-181) from the
+    // largest scale alone.  cov2D = T Sigma T^T + 0.3 I with T = J A (:224-232), so its trace is at most
+    // |A|^2 smax^2 (|J_0|^2 + |J_1|^2) + 0.6, its largest eigenvalue at most ~the trace (det >= 0 up to rounding; the
+    // 0.1 floor of :172 adds < 0.32), and the radius at most 3 sqrt(.) + 1 (ceil).  Padded by 2 % + 1.5 px against
+    // fp32 rounding.  The final tile rows are a subset of the reference rect's rows, which are a subset of
+    // [floor((my - Rb) / 16), floor((my + Rb + 15) / 16)]; if no row of this rank lies in there the gaussian cannot
+    // reach it.  Anything non-finite falls through to the full path.  (Property-tested against row_step = 1:
+    // shards reassemble bit-exactly.)
+    if (!DEBUG && row_step > 1 && !keep_ref_drawn) {
+        const float iz = 1.0f / cm[2];
+        const float u = fminf(cam.limx, fmaxf(-cam.limx, cm[0] * iz)), v = fminf(cam.limy, fmaxf(-cam.limy, cm[1] * iz));
+        const float jx = cam.fx * iz, jy = cam.fy * iz;
+        const float smax = expf(2.0f * fmaxf(ls[0], fmaxf(ls[1], ls[2])));
+        const float trb = cam.w_sigma2 * smax * (jx * jx * (1.0f + u * u) + jy * jy * (1.0f + v * v)) + 0.6f;
+        const float Rb = 3.0f * sqrtf(1.02f * trb + 0.4f) + 1.5f;
+        if (Rb < 1.0e8f && fabsf(my) < 1.0e8f) {
+            const int lo = max((int)floorf((my - Rb) * 0.0625f), 0), hi = (int)floorf((my + Rb + 15.0f) * 0.0625f);
+            int r = (lo - row_begin) % row_step;
+            if (r < 0) r += row_step;
+            const int first = r == 0 ? lo : lo + (row_step - r);
+            if (first > hi) { depth_key[i] = KEY_INVALID; return; }
+        }
+    }
+
+    // cov3D, :357
     const float4 q = reinterpret_cast<const float4 *>(sc.quats)[i];
     float C3[3][3];
     cov3d_of(ls, q, C3);
@@ -65,10 +96,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
     float a = c2[0], b01 = c2[1], b10 = c2[2], c = c2[3];
     if (DEBUG && dbg.cov2d) { dbg.cov2d[4 * i] = a; dbg.cov2d[4 * i + 1] = b01; dbg.cov2d[4 * i + 2] = b10; dbg.cov2d[4 * i + 3] = c; }
     if (culled) a = b01 = b10 = c = 0.0f;  // :388
-
-    // NDC -> pixel, :391
-    const float Wf = (float)cam.W, Hf = (float)cam.H;
-    const float mx = ((ndc_x + 1.0f) * Wf - 1.0f) / 2.0f, my = ((ndc_y + 1.0f) * Hf - 1.0f) / 2.0f;
 
     // compute_covering_bbox, :154-198
     float tb[4], det, spread;
@@ -155,8 +182,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
     }
 
     float rgb[3] = {0.f, 0.f, 0.f};
-    if (!WITH_COLOR) vis[i] = visible ? 1 : 0;  // the colour pass (gsr_preprocess_color) runs later, possibly on another stream
-    if (WITH_COLOR && (visible || (DEBUG && dbg.rgb))) {
+    if (visible || (DEBUG && dbg.rgb)) {
         float sh[48];
         if (SH16) load_sh48_f16(sc.sh, i, sh);
         else load_sh48(reinterpret_cast<const float *>(sc.sh), i, sh);
@@ -192,27 +218,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
     rec[i] = r;
 }
 
-// Second half of stage 1 when it is split (gsr_preprocess_geometry + gsr_preprocess_color): sh_to_rgb
-// (spherical_harmonics.py:27-73) of every gaussian the geometry pass kept, rec[i].q2.yzw <- rgb.  Nothing before the
-// blend reads the colour, so the caller may run this on a second stream while the depth sort and the binning — small,
-// latency-bound launches that leave the chip mostly idle — run on the first.
-template <bool SH16>
-__global__ __launch_bounds__(256) void color_kernel(GsrScene sc, float cx, float cy, float cz, const unsigned char *__restrict__ vis,
-                                                    GaussRec *__restrict__ rec)
-{
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // the literal, not blockDim.x: that would pull in the hidden kernarg block
-    if (i >= sc.n || !vis[i]) return;
-    float sh[48];
-    if (SH16) load_sh48_f16(sc.sh, i, sh);
-    else load_sh48(reinterpret_cast<const float *>(sc.sh), i, sh);
-    const float p[3] = {sc.means[3 * i], sc.means[3 * i + 1], sc.means[3 * i + 2]};
-    const float cc[3] = {cx, cy, cz};
-    float rgb[3];
-    sh_eval(p, sh, cc, sc.sh_degree, rgb);  // rasterize.py:368
-    float *q2 = reinterpret_cast<float *>(&rec[i].q2);
-    q2[1] = rgb[0]; q2[2] = rgb[1]; q2[3] = rgb[2];
-}
-
 static Cam make_cam(const GsrCamera &c)
 {
     Cam k;
@@ -220,11 +225,30 @@ static Cam make_cam(const GsrCamera &c)
     for (int j = 0; j < 3; ++j) k.cc[j] = c.cam_center[j];
     k.fx = c.focal_x; k.fy = c.focal_y; k.limx = c.lim_x; k.limy = c.lim_y;
     k.W = c.width; k.H = c.height;
+    // largest eigenvalue of A^T A (A = w2c[:3,:3]) by power iteration in float64; exactly 1 for a unit qvec.  Only an
+    // upper bound is needed (shard early-out): pad by 1e-3 and never go below the largest column norm.
+    double M[3][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            M[a][b] = 0.0;
+            for (int r = 0; r < 3; ++r) M[a][b] += (double)c.w2c[4 * r + a] * (double)c.w2c[4 * r + b];
+        }
+    double v[3] = {0.6, 0.5, 0.62}, lam = 0.0;
+    for (int it = 0; it < 64; ++it) {
+        double w[3];
+        for (int a = 0; a < 3; ++a) w[a] = M[a][0] * v[0] + M[a][1] * v[1] + M[a][2] * v[2];
+        lam = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        if (!(lam > 0.0)) break;
+        for (int a = 0; a < 3; ++a) v[a] = w[a] / lam;
+    }
+    const double tr = M[0][0] + M[1][1] + M[2][2];  // >= lambda_max >= tr / 3: if the iteration went wrong, fall back to the trace
+    if (!(lam >= tr / 3.0 * 0.999) || !(lam <= tr * 1.001)) lam = tr;
+    k.w_sigma2 = (float)(lam * 1.001 + 1e-12);
     return k;
 }
 
 int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws,
-                      const GsrDebugOut *dbg, bool with_color, int ctrl_reset_words, hipStream_t s)
+                      const GsrDebugOut *dbg, int ctrl_reset_words, hipStream_t s)
 {
     if (scene.n <= 0) {  // no kernel to carry the frame reset
         GSR_HIP(hipMemsetAsync(ws.ctrl, 0, 4 * (size_t)ctrl_reset_words, s));
@@ -235,28 +259,15 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
     GsrDebugOut d;
     memset(&d, 0, sizeof d);
     if (dbg) d = *dbg;
-#define GSR_LAUNCH_PRE(DBG, H16, COL)                                                                                        \
-    hipLaunchKernelGGL((preprocess_kernel<DBG, H16, COL>), dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat,       \
+#define GSR_LAUNCH_PRE(DBG, H16)                                                                                             \
+    hipLaunchKernelGGL((preprocess_kernel<DBG, H16>), dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat,            \
                        opts.no_footprint_cull, opts.tile_row_begin, opts.tile_row_step < 1 ? 1 : opts.tile_row_step,          \
-                       opts.draw_limit > 0 ? 1 : 0, ws.vis, ws.rec, ws.rect, ws.rect8[0], ws.key[0], d,                     \
+                       opts.draw_limit > 0 ? 1 : 0, ws.rec, ws.rect, ws.rect8[0], ws.key[0], d,                             \
                        reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, rect_fits_8bit(ws) ? 1 : 0)
     const bool h16 = scene.sh_dtype == 1;
-    if (!with_color) GSR_LAUNCH_PRE(false, false, false);
-    else if (dbg) { if (h16) GSR_LAUNCH_PRE(true, true, true); else GSR_LAUNCH_PRE(true, false, true); }
-    else          { if (h16) GSR_LAUNCH_PRE(false, true, true); else GSR_LAUNCH_PRE(false, false, true); }
+    if (dbg) { if (h16) GSR_LAUNCH_PRE(true, true); else GSR_LAUNCH_PRE(true, false); }
+    else     { if (h16) GSR_LAUNCH_PRE(false, true); else GSR_LAUNCH_PRE(false, false); }
 #undef GSR_LAUNCH_PRE
-    GSR_HIP(hipGetLastError());
-    return GSR_OK;
-}
-
-int launch_color(const GsrScene &scene, const GsrCamera &cam, const Workspace &ws, hipStream_t s)
-{
-    if (scene.n <= 0) return GSR_OK;
-    const unsigned grid = (unsigned)((scene.n + 255) / 256);
-    if (scene.sh_dtype == 1)
-        hipLaunchKernelGGL(color_kernel<true>, dim3(grid), dim3(256), 0, s, scene, cam.cam_center[0], cam.cam_center[1], cam.cam_center[2], ws.vis, ws.rec);
-    else
-        hipLaunchKernelGGL(color_kernel<false>, dim3(grid), dim3(256), 0, s, scene, cam.cam_center[0], cam.cam_center[1], cam.cam_center[2], ws.vis, ws.rec);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

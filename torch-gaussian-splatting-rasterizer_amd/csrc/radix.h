@@ -1,0 +1,169 @@
+// radix.h — workgroup-level building blocks of the stable LSD radix passes (sort.hip) and of the fused
+// pair-generation + first tile pass (binning.hip).  No reference counterpart: the reference orders gaussians with one
+// torch.sort (rasterize.py:424-425) and has no tile lists.
+//
+// A pass handles a tile of 256 * ITEMS records per workgroup; wave w owns items [w*64*ITEMS, (w+1)*64*ITEMS) in ITEMS
+// rounds of 64 consecutive records, so tile order == (wave, round, lane) order — what keeps every pass stable.
+//   radix_clear        zero the per-wave digit counters and the peer masks
+//   radix_rank         rank[r] = number of EARLIER records of this wave with the same digit (through LDS peer masks)
+//   radix_tile_layout  per-wave exclusive bases + start of every digit inside the reordered tile
+//   radix_reorder      records -> LDS in digit order; the caller then writes digit runs out contiguously
+#pragma once
+#include "gsr_internal.h"
+
+namespace gsr {
+
+constexpr uint32_t RADIX_NO_DIGIT = 0xFFFFFFFFu;  // a record that takes no part in the pass (out of range / dropped)
+
+// How a pass reads its digit: d = ((key - key_base) >> shift) & mask.  dyn_pass >= 0 marks a pass of the DEPTH sort,
+// whose digit geometry is decided on the device from the frame's key range (see sort.hip); -1 = as given here.
+struct PassSpec {
+    int shift;
+    uint32_t mask;
+    uint32_t key_base;
+    uint32_t drop_from;  // DROP passes discard records with key >= drop_from
+    int dyn_pass;
+};
+
+// The depth sort's keys are the IEEE bits of z_cam >= 0.2 (rasterize.py:377): everything below bits(0.2f) is constant.
+constexpr uint32_t DEPTH_KEY_BASE = 0x3E4CCCCDu;  // __float_as_uint(GSR_CULL_Z)
+constexpr int DEPTH_DIGIT_BITS = 9;               // widest digit (512 values) of a depth-sort pass
+
+// Resolves the digit geometry of a pass.  Returns false when a dynamic pass is not needed this frame (uniform).
+__device__ __forceinline__ bool resolve_pass(const PassSpec &a, const FrameCtrl *ctrl, int *shift, uint32_t *mask)
+{
+    if (a.dyn_pass < 0) { *shift = a.shift; *mask = a.mask; return true; }
+    if (a.dyn_pass == 0) { *shift = 0; *mask = (1u << DEPTH_DIGIT_BITS) - 1u; return true; }
+    const uint32_t passes = ctrl->sort_passes, bits = ctrl->sort_key_bits, per = ctrl->sort_bits_rest;
+    if ((uint32_t)a.dyn_pass >= passes) return false;
+    const uint32_t sh = DEPTH_DIGIT_BITS + (uint32_t)(a.dyn_pass - 1) * per;
+    const uint32_t nb = min(per, bits - sh);
+    *shift = (int)sh;
+    *mask = (1u << nb) - 1u;
+    return true;
+}
+
+template <int DIGITS, int ITEMS, bool HAS_V2>
+struct RadixTileSmem {
+    static constexpr int TILE = SORT_THREADS * ITEMS;
+    static_assert(DIGITS == 256 || DIGITS == 512, "one or two digits per thread");
+    static_assert(4 * DIGITS * 8 <= TILE * 4, "the peer masks live in skey until the reorder");
+    uint32_t wave_cnt[4][DIGITS];  // per-wave digit counts, then per-wave exclusive bases
+    uint32_t tile_start[DIGITS];   // start of digit d inside the reordered tile
+    uint32_t skey[TILE];
+    uint32_t sval[TILE];
+    uint32_t sval2[HAS_V2 ? TILE : 1];
+    uint32_t scratch[8];
+    uint32_t n_valid;
+};
+
+template <int DIGITS, int ITEMS, bool HAS_V2>
+__device__ __forceinline__ void radix_clear(RadixTileSmem<DIGITS, ITEMS, HAS_V2> &sm)
+{
+    uint32_t *wc = &sm.wave_cnt[0][0];
+    unsigned long long *pm = reinterpret_cast<unsigned long long *>(sm.skey);
+#pragma unroll
+    for (int i = 0; i < 4 * DIGITS / SORT_THREADS; ++i) {
+        wc[i * SORT_THREADS + threadIdx.x] = 0u;
+        pm[i * SORT_THREADS + threadIdx.x] = 0ull;
+    }
+}
+
+// Ranking: for every record, how many EARLIER records of this wave carry the same digit (earlier round, or same round and
+// lower lane).  The lanes of one round that share a digit find each other through LDS: each ORs its lane bit into
+// peer[digit], reads the mask back and clears it.  DS instructions of one wave execute in program order, so the read sees
+// the whole round's ORs and the next round finds zeros; no barrier, no waiting between rounds.  (The textbook alternative,
+// eight ballots per round with a per-lane 64-bit select after each, measured 8 us of the scatter kernel's 17 us per
+// workgroup: ~50 VALU instructions per round.)  The lowest lane of each group then advances the wave's running count of
+// that digit and hands the old value to its peers.  dig(r) returns the digit of this thread's r-th record or RADIX_NO_DIGIT.
+template <int DIGITS, int ITEMS, bool HAS_V2, typename DigitOf>
+__device__ __forceinline__ void radix_rank(RadixTileSmem<DIGITS, ITEMS, HAS_V2> &sm, DigitOf dig, uint32_t (&rank)[ITEMS])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long *pm = reinterpret_cast<unsigned long long *>(sm.skey) + wave * DIGITS;  // skey is not live until the reorder
+    uint32_t *wc = sm.wave_cnt[wave];
+    const unsigned long long my_bit = 1ull << lane, lt_mask = my_bit - 1ull;
+    // GROUP rounds at a time: all their LDS traffic is issued back to back (three waits per group instead of per round)
+    constexpr int GROUP = 4;
+    static_assert(ITEMS % GROUP == 0, "ITEMS must be a multiple of the ranking group");
+#pragma unroll
+    for (int r0 = 0; r0 < ITEMS; r0 += GROUP) {
+        unsigned long long m[GROUP];
+        uint32_t prior[GROUP];
+#pragma unroll
+        for (int q = 0; q < GROUP; ++q) {
+            const uint32_t d = dig(r0 + q);
+            m[q] = my_bit;
+            if (d != RADIX_NO_DIGIT) {
+                __hip_atomic_fetch_or(&pm[d], my_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                m[q] = __hip_atomic_load(&pm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_store(&pm[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < GROUP; ++q) {
+            const uint32_t d = dig(r0 + q);
+            prior[q] = 0;
+            if (d != RADIX_NO_DIGIT && (m[q] & lt_mask) == 0)
+                prior[q] = __hip_atomic_fetch_add(&wc[d], (uint32_t)__popcll(m[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+#pragma unroll
+        for (int q = 0; q < GROUP; ++q) {
+            const uint32_t d = dig(r0 + q);
+            const uint32_t p = (uint32_t)__shfl((int)prior[q], __ffsll((long long)m[q]) - 1, 64);  // from the group's lowest lane
+            rank[r0 + q] = d != RADIX_NO_DIGIT ? p + (uint32_t)__popcll(m[q] & lt_mask) : RADIX_NO_DIGIT;
+        }
+    }
+}
+
+// After radix_rank + a barrier.  Thread t owns the digits DPT*t .. DPT*t + DPT - 1 (DPT = DIGITS / 256): turns the
+// per-wave counts into per-wave exclusive bases, fills tile_start[], leaves the tile's record count in sm.n_valid and
+// this thread's per-digit counts in cnt[].  Contains two barriers; the caller adds one before using the tables.
+template <int DIGITS, int ITEMS, bool HAS_V2>
+__device__ __forceinline__ void radix_tile_layout(RadixTileSmem<DIGITS, ITEMS, HAS_V2> &sm, uint32_t (&cnt)[DIGITS / SORT_THREADS])
+{
+    constexpr int DPT = DIGITS / SORT_THREADS;
+    const int d0 = DPT * threadIdx.x;
+    uint32_t c[4][DPT], mine = 0;
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) c[w][j] = sm.wave_cnt[w][d0 + j];
+        cnt[j] = c[0][j] + c[1][j] + c[2][j] + c[3][j];
+        mine += cnt[j];
+    }
+    uint32_t total;
+    uint32_t ex = block_excl_scan_256(mine, sm.scratch, &total);
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+        sm.tile_start[d0 + j] = ex;
+        ex += cnt[j];
+        sm.wave_cnt[0][d0 + j] = 0;
+        sm.wave_cnt[1][d0 + j] = c[0][j];
+        sm.wave_cnt[2][d0 + j] = c[0][j] + c[1][j];
+        sm.wave_cnt[3][d0 + j] = c[0][j] + c[1][j] + c[2][j];
+    }
+    if (threadIdx.x == 0) sm.n_valid = total;
+}
+
+// Records -> LDS in digit order (stable).  Needs the tables of radix_tile_layout behind a barrier; the caller adds a
+// barrier before reading skey/sval back.
+template <int DIGITS, int ITEMS, bool HAS_V2, typename DigitOf>
+__device__ __forceinline__ void radix_reorder(RadixTileSmem<DIGITS, ITEMS, HAS_V2> &sm, DigitOf dig, const uint32_t (&rank)[ITEMS],
+                                              const uint32_t (&key)[ITEMS], const uint32_t (&val)[ITEMS],
+                                              const uint32_t (&val2)[HAS_V2 ? ITEMS : 1])
+{
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        if (rank[r] != RADIX_NO_DIGIT) {
+            const uint32_t d = dig(r);
+            const uint32_t pos = sm.tile_start[d] + sm.wave_cnt[wave][d] + rank[r];
+            sm.skey[pos] = key[r];
+            sm.sval[pos] = val[r];
+            if (HAS_V2) sm.sval2[pos] = val2[r];
+        }
+    }
+}
+
+}  // namespace gsr

@@ -1,37 +1,35 @@
-// sort.hip — stable LSD radix sort of (u32 key, u32 value[, u32 value2]) records, up to 8 bits per pass (key bits split evenly over the passes).
+// sort.hip — stable LSD radix sort of (u32 key, u32 value[, u32 value2]) records, up to 9 bits per pass.
 //
 // Used twice per frame (rasterize.py:424-425 is one torch.sort; tile lists have no reference counterpart):
 //   1. depth order:  keys = IEEE bits of z_cam of every gaussian (KEY_INVALID for culled ones, dropped
 //      by pass 0), values = gaussian id (+ its packed tile rect).  Stable from index order => depth ties
 //      resolve by gaussian index.
-//   2. tile lists:   keys = tile id of every (gaussian,tile) pair emitted IN DEPTH ORDER (KEY_INVALID for pairs
-//      the emit kernel culled, dropped by pass 0), values = gaussian id.  A stable sort by tile therefore leaves
-//      every tile's list depth-ordered.
+//   2. tile lists:   keys = (tile row, tile column) of every (gaussian,tile) pair emitted IN DEPTH ORDER, values = gaussian
+//      id.  A stable sort by tile therefore leaves every tile's list depth-ordered.  (Frames up to 4096 px: the first
+//      of its two passes is fused with pair generation in binning.hip; this file runs the second.)
 //
 // Per pass, three launches (no inter-workgroup hand-off inside a launch, so nothing depends on dispatch
-// order or XCD placement):
-//   hist     one workgroup per tile of 256*ITEMS keys: 256-bin digit histogram -> hist[digit][tile]
+// order or XCD placement; a dependent kernel boundary costs ~1.5 us, an in-kernel grid barrier 4-10 us):
+//   hist     one workgroup per tile of 256*ITEMS keys: digit histogram -> hist[digit][tile]
 //   rowscan  one workgroup per digit: exclusive scan of its row in place, row total -> digit_tot[digit]
 //   scatter  one workgroup per tile: per-wave ranking through LDS peer masks -> tile reordered by digit in LDS -> digit
-//            runs written out contiguously (coalesced), position = digit base + scanned hist + rank in run
-// The element count lives in device memory (n_dev): grids are sized by the host-side bound and
-// surplus workgroups fall through.  4096-key tiles (16 keys per thread): 2048-key tiles measured slower, the
-// fixed per-workgroup costs (7 barriers, two 256-wide scans, 512 table loads) dominate small tiles.
+//            runs written out contiguously (coalesced), position = digit base + scanned hist + rank in run   (radix.h)
+// The element count lives in device memory (n_dev): grids are sized by the host-side bound and surplus workgroups fall
+// through.  4096-key tiles (16 keys per thread): 2048-key tiles measured slower, the fixed per-workgroup costs dominate.
+//
+// Depth sort in three passes instead of four.  z_cam >= 0.2, so a key's sign and high exponent bits never vary: the sort
+// runs on key - bits(0.2f), and only on the bits the frame actually uses.  Pass 0 always takes 9 bits; its histogram
+// kernel, which reads every key anyway, also reduces the largest valid key (one guarded atomicMax per workgroup); the
+// pass-0 rowscan turns that into the plan for the remaining passes (FrameCtrl.sort_*): the B - 9 remaining bits split
+// evenly over as few passes of <= 9 bits as possible.  A scene whose depths span 0.2 .. 83 (B <= 27) sorts in 9 + 9 + 9;
+// the launch sequence is fixed at four passes (the host cannot know B without a sync) and the kernels of an unused pass
+// return at once.  Consumers find the sorted buffer from the plan (sort_passes & 1).
 // Roofline: HBM.  Per pass per element: 4 B (hist) + 8..12 B read + 8..12 B written.
 #include <algorithm>
 #include "gsr_internal.h"
+#include "radix.h"
 
 namespace gsr {
-
-#ifdef GSR_SORT_TRACE  // tools/sort_trace.py: per-workgroup phase stamps of the scatter kernel (100 MHz wall clock)
-__device__ uint32_t g_sort_trace[16384 * 8];
-#ifndef GSR_SORT_TRACE_DROP
-#define GSR_SORT_TRACE_DROP 0
-#endif
-#define GSR_STAMP(k) do { if (DROP_INVALID == (GSR_SORT_TRACE_DROP != 0) && !HAS_V2 && threadIdx.x == 0 && blockIdx.x < 16384) g_sort_trace[blockIdx.x * 8 + (k)] = (uint32_t)wall_clock64(); } while (0)
-#else
-#define GSR_STAMP(k) do {} while (0)
-#endif
 
 __device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t n_bound)
 {
@@ -40,97 +38,152 @@ __device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t n
     return n < n_bound ? n : n_bound;
 }
 
-template <bool DROP_INVALID, int ITEMS>
+template <int DIGITS, bool DROP, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t *__restrict__ keys, const uint32_t *n_dev,
-                                                                  uint32_t n_bound, int shift, uint32_t mask,
+                                                                  uint32_t n_bound, PassSpec ps, FrameCtrl *ctrl,
                                                                   uint32_t *__restrict__ hist, int hist_blocks)
 {
-    __shared__ uint32_t h[256];
+    constexpr int TILE = SORT_THREADS * ITEMS;
+    __shared__ uint32_t h[DIGITS];
+    __shared__ uint32_t s_max;
+    int shift;
+    uint32_t mask;
+    if (!resolve_pass(ps, ctrl, &shift, &mask)) return;  // uniform: this depth-sort pass is not needed
     const uint32_t n = load_count(n_dev, n_bound);
-    h[threadIdx.x] = 0;
+    const uint32_t base = blockIdx.x * (uint32_t)TILE;
+    if (base >= n) return;  // rowscan and scatter stop at the live tiles too
+#pragma unroll
+    for (int j = 0; j < DIGITS / SORT_THREADS; ++j) h[j * SORT_THREADS + threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_max = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
-    if (base + SORT_THREADS * ITEMS <= n) {  // full tile: unguarded loads, all in flight together
+    uint32_t kmax = 0;
+    if (n - base >= (uint32_t)TILE) {  // full tile: unguarded loads, all in flight together
         uint32_t k[ITEMS];
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) k[r] = keys[base + r * SORT_THREADS + threadIdx.x];
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r)
-            if (!DROP_INVALID || k[r] != KEY_INVALID) atomicAdd(&h[(k[r] >> shift) & mask], 1u);
-    } else if (base < n) {
+            if (!DROP || k[r] < ps.drop_from) {
+                atomicAdd(&h[((k[r] - ps.key_base) >> shift) & mask], 1u);
+                kmax = max(kmax, k[r]);
+            }
+    } else {
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const uint32_t idx = base + r * SORT_THREADS + threadIdx.x;
             if (idx < n) {
                 const uint32_t k = keys[idx];
-                if (!DROP_INVALID || k != KEY_INVALID) atomicAdd(&h[(k >> shift) & mask], 1u);
+                if (!DROP || k < ps.drop_from) {
+                    atomicAdd(&h[((k - ps.key_base) >> shift) & mask], 1u);
+                    kmax = max(kmax, k);
+                }
             }
         }
     }
+    if (ps.dyn_pass == 0) {  // key range of the frame: wave max -> workgroup max -> at most one device atomic, usually none
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(&s_max, kmax);
+    }
     __syncthreads();
-    hist[(size_t)threadIdx.x * hist_blocks + blockIdx.x] = h[threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < DIGITS / SORT_THREADS; ++j) {
+        const int d = j * SORT_THREADS + threadIdx.x;
+        hist[(size_t)d * hist_blocks + blockIdx.x] = h[d];
+    }
+    if (ps.dyn_pass == 0 && threadIdx.x == 0) {
+        const uint32_t m = s_max;
+        // the running maximum only grows: a stale (smaller) value read here costs one redundant atomic, never a wrong result
+        if (m > __hip_atomic_load(&ctrl->depth_key_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ctrl->depth_key_max, m);
+    }
 }
 
-// One workgroup per digit row.  Rows are `hist_blocks` long; only the first `nblk` entries are live.
-__global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t *__restrict__ hist, int hist_blocks, int nblk,
-                                                            uint32_t *__restrict__ digit_tot)
+// One workgroup per digit row.  Rows are `hist_blocks` long; only the entries of the live tiles are scanned.
+// The pass-0 rowscan of the depth sort also fixes the plan of the remaining passes (see the header).
+template <int TILE>
+__global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t *__restrict__ hist, int hist_blocks, const uint32_t *n_dev,
+                                                            uint32_t n_bound, PassSpec ps, FrameCtrl *ctrl)
 {
-    __shared__ uint32_t scratch[8];
+    __shared__ unsigned long long wsum[4];
+    int shift;
+    uint32_t mask;
+    if (!resolve_pass(ps, ctrl, &shift, &mask)) return;
+    if (ps.dyn_pass == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t kmax = ctrl->depth_key_max;
+        const uint32_t span = kmax > DEPTH_KEY_BASE ? kmax - DEPTH_KEY_BASE : 0u;
+        const uint32_t bits = span ? 32u - (uint32_t)__clz((int)span) : 1u;
+        const uint32_t rest = bits > DEPTH_DIGIT_BITS ? bits - DEPTH_DIGIT_BITS : 0u;
+        const uint32_t rest_passes = (rest + DEPTH_DIGIT_BITS - 1) / DEPTH_DIGIT_BITS;
+        ctrl->sort_passes = 1u + rest_passes;
+        ctrl->sort_key_bits = bits;
+        ctrl->sort_bits_rest = rest_passes ? (rest + rest_passes - 1) / rest_passes : 0u;
+        ctrl->depth_key_max = 0u;  // ready for the next frame's pass-0 histogram (stream-ordered behind this kernel)
+    }
+    const uint32_t n = load_count(n_dev, n_bound);
+    const int nblk = (int)(((unsigned long long)n + TILE - 1) / TILE);
     uint32_t *row = hist + (size_t)blockIdx.x * hist_blocks;
-    uint32_t carry = 0;
+    // 64-bit running sums, stored saturated: the fused binning's column totals may in principle pass 2^32 (then every
+    // position derived from them lies beyond max_pairs and the frame is reported as overflowed, never written out of bounds)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long carry = 0;
     for (int base = 0; base < nblk; base += 1024) {
         const int i0 = base + threadIdx.x * 4;
         uint32_t v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = (i0 + j < nblk) ? row[i0 + j] : 0u;
-        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
-        uint32_t total;
-        uint32_t ex = block_excl_scan_256(mine, scratch, &total) + carry;
+        const unsigned long long mine = (unsigned long long)v[0] + v[1] + v[2] + v[3];
+        unsigned long long incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        unsigned long long wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const unsigned long long sw = wsum[w];
+            if (w < wave) wbase += sw;
+            total += sw;
+        }
+        __syncthreads();
+        unsigned long long ex = carry + wbase + (incl - mine);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (i0 + j < nblk) row[i0 + j] = ex;
+            if (i0 + j < nblk) row[i0 + j] = ex > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ex;
             ex += v[j];
         }
         carry += total;
     }
-    if (threadIdx.x == 0) digit_tot[blockIdx.x] = carry;
+    if (threadIdx.x == 0) ctrl->digit_tot[blockIdx.x] = carry > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)carry;
 }
 
-template <bool DROP_INVALID, int ITEMS, bool HAS_V2, bool INDEX_VALS>
+template <int DIGITS, bool DROP, int ITEMS, bool HAS_V2, bool INDEX_VALS>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint32_t *__restrict__ vals2_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t *__restrict__ vals2_out, const uint32_t *n_dev,
-    uint32_t n_bound, int shift, uint32_t mask, const uint32_t *__restrict__ hist, int hist_blocks,
-    const uint32_t *__restrict__ digit_tot, uint32_t *n_out)
+    uint32_t n_bound, PassSpec ps, const FrameCtrl *ctrl, const uint32_t *__restrict__ hist, int hist_blocks, uint32_t *n_out)
 {
-    constexpr int TILE = SORT_THREADS * ITEMS;
-    __shared__ uint32_t wave_cnt[4][256];   // per-wave digit counts, then per-wave exclusive bases
-    __shared__ uint32_t digit_base[256];    // global position of this tile's run of digit d
-    __shared__ uint32_t tile_start[256];    // start of digit d inside the reordered tile
-    __shared__ uint32_t skey[TILE];
-    __shared__ uint32_t sval[TILE];
-    __shared__ uint32_t sval2[HAS_V2 ? TILE : 1];
-    __shared__ uint32_t scratch[8];
-    __shared__ uint32_t s_valid;
+    using Smem = RadixTileSmem<DIGITS, ITEMS, HAS_V2>;
+    constexpr int TILE = Smem::TILE;
+    constexpr int DPT = DIGITS / SORT_THREADS;
+    __shared__ Smem sm;
+    __shared__ uint32_t digit_base[DIGITS];  // global position of this tile's run of digit d
 
+    int shift;
+    uint32_t mask;
+    if (!resolve_pass(ps, ctrl, &shift, &mask)) return;  // uniform
     const uint32_t n = load_count(n_dev, n_bound);
-    const uint32_t base = blockIdx.x * TILE;
+    const uint32_t base = blockIdx.x * (uint32_t)TILE;
     if (base >= n) return;  // uniform per workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    GSR_STAMP(0);
 
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        wave_cnt[w][tid] = 0;
-        reinterpret_cast<unsigned long long *>(skey)[w * 256 + tid] = 0ull;  // peer masks (see the ranking below)
-    }
+    radix_clear(sm);
     __syncthreads();
 
-    // wave w owns items [w*64*ITEMS, (w+1)*64*ITEMS) of the tile, ITEMS rounds of 64 consecutive keys:
-    // tile order == (wave, round, lane) order, which is what keeps the sort stable.
     uint32_t key[ITEMS], val[ITEMS], val2[HAS_V2 ? ITEMS : 1], rank[ITEMS];
-    if (base + TILE <= n) {  // full tile (all but the last workgroup): unguarded loads, all in flight together
+    if (n - base >= (uint32_t)TILE) {  // full tile (all but the last workgroup): unguarded loads, all in flight together
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
@@ -148,177 +201,131 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
             if (HAS_V2) val2[r] = in ? vals2_in[idx] : 0u;
         }
     }
-#ifdef GSR_SORT_TRACE
-    { uint32_t acc = 0;
-#pragma unroll
-      for (int r = 0; r < ITEMS; ++r) acc += key[r] + val[r];
-      asm volatile("" ::"v"(acc)); }  // wait for the loads
-#endif
-    GSR_STAMP(1);
-    {
-    // Ranking: for every key, how many EARLIER keys of this wave carry the same digit (earlier round, or same round and
-    // lower lane) -- what keeps the sort stable.  The lanes of one round that share a digit find each other through LDS:
-    // each ORs its lane bit into peer[digit], reads the mask back and clears it.  DS instructions of one wave execute in
-    // program order, so the read sees the whole round's ORs and the next round finds zeros; no barrier, no waiting between
-    // rounds.  (The textbook alternative, eight ballots per round with a per-lane 64-bit select after each, measured
-    // 8 us of this kernel's 17 us per workgroup: ~50 VALU instructions per round.)  The lowest lane of each group then
-    // advances the wave's running count of that digit and hands the old value to its peers.
-    unsigned long long *pm = reinterpret_cast<unsigned long long *>(skey) + wave * 256;  // skey is not live until the reorder
-    uint32_t *wc = wave_cnt[wave];
-    const unsigned long long my_bit = 1ull << lane;
-    // GROUP rounds at a time: all their LDS traffic is issued back to back (three waits per group instead of per round)
-    constexpr int GROUP = 4;
-    static_assert(ITEMS % GROUP == 0, "ITEMS must be a multiple of the ranking group");
-#pragma unroll
-    for (int r0 = 0; r0 < ITEMS; r0 += GROUP) {
-        unsigned long long m[GROUP];
-        uint32_t prior[GROUP];
-#pragma unroll
-        for (int q = 0; q < GROUP; ++q) {
-            const int r = r0 + q;
-            const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
-            const bool valid = (idx < n) && (!DROP_INVALID || key[r] != KEY_INVALID);
-            const uint32_t d = (key[r] >> shift) & mask;
-            m[q] = my_bit;
-            if (valid) {
-                __hip_atomic_fetch_or(&pm[d], my_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                m[q] = __hip_atomic_load(&pm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_store(&pm[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < GROUP; ++q) {
-            const int r = r0 + q;
-            const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
-            const bool valid = (idx < n) && (!DROP_INVALID || key[r] != KEY_INVALID);
-            const uint32_t d = (key[r] >> shift) & mask;
-            prior[q] = 0;
-            if (valid && (m[q] & lt_mask) == 0)
-                prior[q] = __hip_atomic_fetch_add(&wc[d], (uint32_t)__popcll(m[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
-#pragma unroll
-        for (int q = 0; q < GROUP; ++q) {
-            const int r = r0 + q;
-            const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
-            const bool valid = (idx < n) && (!DROP_INVALID || key[r] != KEY_INVALID);
-            const uint32_t p = (uint32_t)__shfl((int)prior[q], __ffsll((long long)m[q]) - 1, 64);  // from the group's lowest lane
-            rank[r] = valid ? p + (uint32_t)__popcll(m[q] & lt_mask) : 0xFFFFFFFFu;
-        }
-    }
-    }
+    auto dig = [&](int r) -> uint32_t {
+        const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
+        const bool valid = (idx < n) && (!DROP || key[r] < ps.drop_from);
+        return valid ? ((key[r] - ps.key_base) >> shift) & mask : RADIX_NO_DIGIT;
+    };
+    radix_rank(sm, dig, rank);
     __syncthreads();
-    GSR_STAMP(2);
 
-    // digit d = tid: per-wave exclusive bases, tile digit starts, global digit bases
-    {
-        const uint32_t c0 = wave_cnt[0][tid], c1 = wave_cnt[1][tid], c2 = wave_cnt[2][tid], c3 = wave_cnt[3][tid];
-        const uint32_t cnt = c0 + c1 + c2 + c3;
-        uint32_t tile_total, all_total;
-        const uint32_t ts = block_excl_scan_256(cnt, scratch, &tile_total);
-        const uint32_t gs = block_excl_scan_256(digit_tot[tid], scratch, &all_total);
-        wave_cnt[0][tid] = 0; wave_cnt[1][tid] = c0; wave_cnt[2][tid] = c0 + c1; wave_cnt[3][tid] = c0 + c1 + c2;
-        tile_start[tid] = ts;
-        digit_base[tid] = gs + hist[(size_t)tid * hist_blocks + blockIdx.x];
-        if (tid == 0) {
-            s_valid = tile_total;
-            if (n_out != nullptr && blockIdx.x == 0) *n_out = all_total;
-        }
-    }
-    __syncthreads();
-    GSR_STAMP(3);
-
+    uint32_t cnt[DPT];
+    radix_tile_layout(sm, cnt);
+    {  // global digit bases: exclusive scan of the digit totals + this tile's entry of the scanned histogram
+        const int d0 = DPT * tid;
+        uint32_t tot[DPT], mine = 0;
 #pragma unroll
-    for (int r = 0; r < ITEMS; ++r) {
-        if (rank[r] != 0xFFFFFFFFu) {
-            const uint32_t d = (key[r] >> shift) & mask;
-            const uint32_t pos = tile_start[d] + wave_cnt[wave][d] + rank[r];
-            skey[pos] = key[r];
-            sval[pos] = val[r];
-            if (HAS_V2) sval2[pos] = val2[r];
+        for (int j = 0; j < DPT; ++j) { tot[j] = ctrl->digit_tot[d0 + j]; mine += tot[j]; }
+        uint32_t all_total;
+        uint32_t gs = block_excl_scan_256(mine, sm.scratch, &all_total);
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) {
+            digit_base[d0 + j] = gs + hist[(size_t)(d0 + j) * hist_blocks + blockIdx.x];
+            gs += tot[j];
         }
+        if (n_out != nullptr && blockIdx.x == 0 && tid == 0) *n_out = all_total;
     }
     __syncthreads();
 
-    GSR_STAMP(4);
-    const uint32_t nvalid = s_valid;
+    radix_reorder(sm, dig, rank, key, val, val2);
+    __syncthreads();
+
+    const uint32_t nvalid = sm.n_valid;
     for (uint32_t i = tid; i < nvalid; i += SORT_THREADS) {
-        const uint32_t k = skey[i];
-        const uint32_t d = (k >> shift) & mask;
-        const uint32_t gpos = digit_base[d] + (i - tile_start[d]);
+        const uint32_t k = sm.skey[i];
+        const uint32_t d = ((k - ps.key_base) >> shift) & mask;
+        const uint32_t gpos = digit_base[d] + (i - sm.tile_start[d]);
         keys_out[gpos] = k;
-        vals_out[gpos] = sval[i];
-        if (HAS_V2) vals2_out[gpos] = sval2[i];
+        vals_out[gpos] = sm.sval[i];
+        if (HAS_V2) vals2_out[gpos] = sm.sval2[i];
     }
-#ifdef GSR_SORT_TRACE
-    __syncthreads();
-#endif
-    GSR_STAMP(5);
 }
 
-template <int ITEMS, bool HAS_V2>
-static int sort_passes(uint32_t *const key[2], uint32_t *const val[2], uint32_t *const val2[2], const uint32_t *n_dev,
-                       int64_t n_bound, int key_bits, bool drop_invalid_first, bool index_values,
-                       uint32_t *n_out, const Workspace &ws, int *result_buf, hipStream_t s)
+// One pass = hist + rowscan + scatter.  `first` = pass 0 of a sort (may drop, may synthesise the index payload).
+template <int DIGITS, int ITEMS, bool HAS_V2>
+static void launch_pass(const uint32_t *kin, const uint32_t *vin, const uint32_t *v2in, uint32_t *kout, uint32_t *vout, uint32_t *v2out,
+                        const uint32_t *cnt_dev, int64_t n_bound, const PassSpec &ps, bool drop, bool ident, uint32_t *n_out,
+                        const Workspace &ws, hipStream_t s)
 {
     constexpr int TILE = SORT_THREADS * ITEMS;
     const int nblk = (int)((n_bound + TILE - 1) / TILE);
-    if (nblk > ws.hist_blocks) { set_error("radix sort: %d tiles exceed the histogram stride %d", nblk, ws.hist_blocks); return GSR_ERR_WORKSPACE; }
-    int cur = 0;
-    const uint32_t *cnt_dev = n_dev;
-    uint32_t *dt = ws.ctrl->digit_tot;
-    // digits: as few passes as 8-bit digits allow, the key bits split evenly over them (13 tile-id bits -> 7 + 6, not 8 + 5:
-    // fewer digit values per pass mean longer runs per workgroup, i.e. fuller 128-B lines in the scattered writes)
-    const int passes = (key_bits + 7) / 8;
-    const int bits_pp = (key_bits + passes - 1) / passes;
-    for (int p = 0; p < passes; ++p) {
-        const int shift = bits_pp * p;
-        const uint32_t mask = (1u << std::min(bits_pp, key_bits - shift)) - 1u;
-        const bool drop = drop_invalid_first && p == 0;
-        const uint32_t *v2i = HAS_V2 ? val2[cur] : nullptr;
-        uint32_t *v2o = HAS_V2 ? val2[cur ^ 1] : nullptr;
-        const bool ident = index_values && p == 0;  // pass 0 can synthesise value = index instead of loading it
-#define GSR_HIST(DROP)                                                                                                             \
-    hipLaunchKernelGGL((radix_hist_kernel<DROP, ITEMS>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], cnt_dev, (uint32_t)n_bound, \
-                       shift, mask, ws.hist, ws.hist_blocks)
+    const uint32_t nb = (uint32_t)n_bound;
 #define GSR_SCATTER(DROP, IDENT)                                                                                                   \
-    hipLaunchKernelGGL((radix_scatter_kernel<DROP, ITEMS, HAS_V2, IDENT>), dim3(nblk), dim3(SORT_THREADS), 0, s, key[cur], val[cur], \
-                       v2i, key[cur ^ 1], val[cur ^ 1], v2o, cnt_dev, (uint32_t)n_bound, shift, mask, ws.hist, ws.hist_blocks, dt,         \
-                       drop ? n_out : (uint32_t *)nullptr)
-        if (drop) {
-            GSR_HIST(true);
-            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, s, ws.hist, ws.hist_blocks, nblk, dt);
-            if (ident) GSR_SCATTER(true, true); else GSR_SCATTER(true, false);
-            if (n_out) cnt_dev = n_out;  // later passes only see the survivors
-        } else {
-            GSR_HIST(false);
-            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, s, ws.hist, ws.hist_blocks, nblk, dt);
-            if (ident) GSR_SCATTER(false, true); else GSR_SCATTER(false, false);
-        }
+    hipLaunchKernelGGL((radix_scatter_kernel<DIGITS, DROP, ITEMS, HAS_V2, IDENT>), dim3(nblk), dim3(SORT_THREADS), 0, s, kin, vin, v2in, \
+                       kout, vout, v2out, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks, n_out)
+    if (drop) hipLaunchKernelGGL((radix_hist_kernel<DIGITS, true, ITEMS>), dim3(nblk), dim3(SORT_THREADS), 0, s, kin, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks);
+    else hipLaunchKernelGGL((radix_hist_kernel<DIGITS, false, ITEMS>), dim3(nblk), dim3(SORT_THREADS), 0, s, kin, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks);
+    hipLaunchKernelGGL(radix_rowscan_kernel<TILE>, dim3(DIGITS), dim3(256), 0, s, ws.hist, ws.hist_blocks, cnt_dev, nb, ps, ws.ctrl);
+    if (drop) { if (ident) GSR_SCATTER(true, true); else GSR_SCATTER(true, false); }
+    else      { if (ident) GSR_SCATTER(false, true); else GSR_SCATTER(false, false); }
 #undef GSR_SCATTER
-#undef GSR_HIST
-        GSR_HIP(hipGetLastError());
+}
+
+void launch_rowscan_blocks(const Workspace &ws, int rows, int block, const uint32_t *n_dev, int64_t n_bound, hipStream_t s)
+{
+    const PassSpec ps = {0, 0u, 0u, 0u, -1};
+    if (block == PAIR_BLOCK)
+        hipLaunchKernelGGL(radix_rowscan_kernel<PAIR_BLOCK>, dim3(rows), dim3(256), 0, s, ws.hist, ws.hist_blocks, n_dev, (uint32_t)n_bound, ps, ws.ctrl);
+    else
+        hipLaunchKernelGGL(radix_rowscan_kernel<SORT_THREADS * PAIR_SORT_ITEMS>, dim3(rows), dim3(256), 0, s, ws.hist, ws.hist_blocks, n_dev,
+                           (uint32_t)n_bound, ps, ws.ctrl);
+}
+
+// Depth order of the gaussians (rasterize.py:424-425).  Always four passes enqueued, 3 run on ordinary scenes (header).
+// Afterwards FrameCtrl.n_visible = V and the sorted ids / packed rects are in val[p] / rect8[p], p = sort_passes & 1.
+int launch_depth_sort(const Workspace &ws, bool packed_rect, hipStream_t s)
+{
+    if (ws.n <= 0) return GSR_OK;
+    constexpr int TILE = SORT_THREADS * DEPTH_SORT_ITEMS;
+    const int nblk = (int)((ws.n + TILE - 1) / TILE);
+    if (nblk > ws.hist_blocks) { set_error("radix sort: %d tiles exceed the histogram stride %d", nblk, ws.hist_blocks); return GSR_ERR_WORKSPACE; }
+    const uint32_t *cnt_dev = nullptr;
+    for (int p = 0; p < 4; ++p) {
+        const PassSpec ps = {0, 0u, DEPTH_KEY_BASE, KEY_INVALID, p};
+        const int in = p & 1, out = in ^ 1;
+        const bool first = p == 0;
+        if (packed_rect)
+            launch_pass<512, DEPTH_SORT_ITEMS, true>(ws.key[in], ws.val[in], ws.rect8[in], ws.key[out], ws.val[out], ws.rect8[out], cnt_dev, ws.n, ps,
+                                                     first, first, first ? &ws.ctrl->n_visible : nullptr, ws, s);
+        else
+            launch_pass<512, DEPTH_SORT_ITEMS, false>(ws.key[in], ws.val[in], nullptr, ws.key[out], ws.val[out], nullptr, cnt_dev, ws.n, ps,
+                                                      first, first, first ? &ws.ctrl->n_visible : nullptr, ws, s);
+        cnt_dev = &ws.ctrl->n_visible;  // later passes only see the survivors
+    }
+    GSR_HIP(hipGetLastError());
+    return GSR_OK;
+}
+
+// Stable sort of the (tile key, gaussian id) pairs over key bits [first_bit, key_bits), 8 bits or fewer per pass, the bits
+// split evenly (13 tile-id bits sort as 7 + 6, not 8 + 5: with 128 digit values a workgroup's runs in the first,
+// far-scattering pass are 32 entries = one full 128-B line per array instead of half a line).  The first pass run here
+// drops keys >= drop_from (pairs culled at emission) and leaves the survivor count in *n_out.  in_buf: which of
+// pkey[]/pval[] holds the input; *result_buf: which holds the output.
+int launch_pair_sort(const Workspace &ws, int in_buf, const uint32_t *n_dev, int first_bit, int key_bits, uint32_t drop_from,
+                     uint32_t *n_out, int *result_buf, hipStream_t s)
+{
+    *result_buf = in_buf;
+    if (ws.max_pairs <= 0 || key_bits <= first_bit) return GSR_OK;
+    constexpr int TILE = SORT_THREADS * PAIR_SORT_ITEMS;
+    const int nblk = (int)((ws.max_pairs + TILE - 1) / TILE);
+    if (nblk > ws.hist_blocks) { set_error("radix sort: %d tiles exceed the histogram stride %d", nblk, ws.hist_blocks); return GSR_ERR_WORKSPACE; }
+    const int bits = key_bits - first_bit;
+    const int passes = (bits + 7) / 8;
+    const int bits_pp = (bits + passes - 1) / passes;
+    int cur = in_buf;
+    const uint32_t *cnt_dev = n_dev;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = first_bit + bits_pp * p;
+        const PassSpec ps = {shift, (1u << std::min(bits_pp, key_bits - shift)) - 1u, 0u, drop_from, -1};
+        const bool first = p == 0;
+        launch_pass<256, PAIR_SORT_ITEMS, false>(ws.pkey[cur], ws.pval[cur], nullptr, ws.pkey[cur ^ 1], ws.pval[cur ^ 1], nullptr, cnt_dev,
+                                                 ws.max_pairs, ps, first, false, first ? n_out : nullptr, ws, s);
+        if (first && n_out) cnt_dev = n_out;
         cur ^= 1;
     }
+    GSR_HIP(hipGetLastError());
     *result_buf = cur;
     return GSR_OK;
 }
 
-int launch_radix_sort(uint32_t *const key[2], uint32_t *const val[2], uint32_t *const val2[2], const uint32_t *n_dev,
-                      int64_t n_bound, int key_bits, bool drop_invalid_first, bool index_values,
-                      uint32_t *n_out, int items_per_thread, const Workspace &ws, int *result_buf, hipStream_t s)
-{
-    *result_buf = 0;
-    if (n_bound <= 0 || key_bits <= 0) return GSR_OK;
-    if (items_per_thread != 16) { set_error("radix sort: unsupported items_per_thread %d", items_per_thread); return GSR_ERR_BAD_ARG; }
-    return val2 ? sort_passes<16, true>(key, val, val2, n_dev, n_bound, key_bits, drop_invalid_first, index_values, n_out, ws, result_buf, s)
-                : sort_passes<16, false>(key, val, val2, n_dev, n_bound, key_bits, drop_invalid_first, index_values, n_out, ws, result_buf, s);
-}
-
 }  // namespace gsr
-
-#ifdef GSR_SORT_TRACE
-extern "C" int gsr_debug_sort_trace(void *dst, size_t bytes)
-{
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gsr::g_sort_trace), bytes < sizeof(gsr::g_sort_trace) ? bytes : sizeof(gsr::g_sort_trace));
-}
-#endif

@@ -105,17 +105,11 @@ def shard_rows(height: int, begin: int, step: int) -> int:
 class Rasterizer:
     """Owns the scratch workspace for one scene and renders frames of it."""
 
-    def __init__(self, scene: GaussianScene, max_pairs: Optional[int] = None, overlap: bool = False):
-        """overlap: run the SH colour half of stage 1 on a second stream, concurrently with the depth sort and the binning
-        (nothing before the blend reads the colour).  Bit-identical frames.  Off by default: measured on MI355X / ROCm 7.2
-        the two streams' kernels do not actually overlap and the split halves cost more than the fused kernel
-        (1.76 vs 1.66 ms per bench frame)."""
+    def __init__(self, scene: GaussianScene, max_pairs: Optional[int] = None):
         self.scene = scene
-        self.max_pairs = int(max_pairs) if max_pairs else max(1 << 20, 8 * scene.n)
-        self.overlap = bool(overlap)
-        self._aux: Optional[torch.cuda.Stream] = None
-        self._ev_geo = self._ev_col = None
+        self.max_pairs = min(_lib.GSR_MAX_PAIRS, int(max_pairs) if max_pairs else max(1 << 20, 8 * scene.n))
         self._ws: Optional[torch.Tensor] = None
+        self._rendered = True
         self._ws_key = None
         self.last_stats: Optional[Dict[str, int]] = None
 
@@ -127,6 +121,9 @@ class Rasterizer:
             self._ws = None  # free the old one first
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.scene.device)
             assert self._ws.data_ptr() % 256 == 0
+            # the counter block at the head starts defined: stats() before any frame reads zeros, and the depth sort's
+            # running key maximum (the one word libgsr carries from frame to frame) starts at 0 instead of garbage
+            self._ws[: min(4096, nbytes)].zero_()
             self._ws_key = key
         return self._ws
 
@@ -153,32 +150,20 @@ class Rasterizer:
         elif tuple(out.shape) != shape or out.dtype != dtype or not out.is_contiguous() or not out.is_cuda:
             raise ValueError(f"out must be a contiguous {dtype} CUDA tensor of shape {shape}")
         if out.numel() == 0:  # a shard that owns no tile row (more ranks than tile rows): nothing to render
+            self._rendered = False
             return out
+        self._rendered = True
         sc = self.scene.c_struct()
         tptr = final_T.data_ptr() if final_T is not None else None
-        if not self.overlap:
-            check(lib.gsr_render_forward(C.byref(sc), C.byref(cam), C.byref(opts), self.max_pairs, ws.data_ptr(), ws.numel(),
-                                         out.data_ptr(), tptr, _stream_ptr(self.scene.device)))
-            return out
-        dev = self.scene.device
-        if self._aux is None:
-            self._aux = torch.cuda.Stream(dev)
-            self._ev_geo, self._ev_col = torch.cuda.Event(), torch.cuda.Event()
-        main = torch.cuda.current_stream(dev)
-        mp, ap = int(main.cuda_stream), int(self._aux.cuda_stream)
-        wp, wn, n = ws.data_ptr(), ws.numel(), self.scene.n
-        check(lib.gsr_preprocess_geometry(C.byref(sc), C.byref(cam), C.byref(opts), wp, wn, mp))
-        self._ev_geo.record(main)
-        self._aux.wait_event(self._ev_geo)
-        check(lib.gsr_preprocess_color(C.byref(sc), C.byref(cam), C.byref(opts), wp, wn, ap))   # second stream ...
-        self._ev_col.record(self._aux)
-        check(lib.gsr_bin_sort(n, C.byref(cam), C.byref(opts), self.max_pairs, wp, wn, mp))        # ... under the sorts
-        main.wait_event(self._ev_col)
-        check(lib.gsr_blend(n, C.byref(cam), C.byref(opts), self.max_pairs, wp, wn, out.data_ptr(), tptr, mp))
+        check(lib.gsr_render_forward(C.byref(sc), C.byref(cam), C.byref(opts), self.max_pairs, ws.data_ptr(), ws.numel(),
+                                     out.data_ptr(), tptr, _stream_ptr(self.scene.device)))
         return out
 
     def stats(self) -> Dict[str, int]:
         """Counters of the last enqueued frame (synchronises the stream).  Raises GsrPairOverflow on overflow."""
+        if not self._rendered:  # the last enqueue was an empty shard: no kernel ran, nothing to read
+            self.last_stats = {k: 0 for k, _ in GsrStats._fields_ if not k.startswith("_")}
+            return self.last_stats
         st = GsrStats()
         rc = lib.gsr_read_stats(self._ws.data_ptr(), self._ws.numel(), C.byref(st), _stream_ptr(self.scene.device))
         self.last_stats = st.as_dict()
@@ -199,9 +184,9 @@ class Rasterizer:
                 self.stats()
             except _lib.GsrPairOverflow:
                 need = int(self.last_stats["n_pairs_bbox"])
-                if need >= 0xFFFFFFF0:
+                if need >= _lib.GSR_MAX_PAIRS:
                     raise
-                self.max_pairs = int(min(0xFFFFFFF0, need + need // 8 + 1024))
+                self.max_pairs = int(min(_lib.GSR_MAX_PAIRS, need + need // 8 + 1024))
                 continue
             return (img, final_T) if return_T else img
 
@@ -231,14 +216,14 @@ class Rasterizer:
                 return out
             except _lib.GsrPairOverflow:
                 need = int(self.last_stats["n_pairs_bbox"])
-                self.max_pairs = int(min(0xFFFFFFF0, need + need // 4 + 1024))
+                self.max_pairs = int(min(_lib.GSR_MAX_PAIRS, need + need // 4 + 1024))
 
     def fit_pairs(self, cam: GsrCamera, opts: Optional[GsrOptions] = None, slack: float = 1.25) -> int:
         """Size the pair buffers to this view: one probing frame, then max_pairs = slack * D (+ margin).
         Sort grids and histogram tables scale with max_pairs, so a snug bound is also the fast one."""
         self.render(cam, opts)
         need = int(self.last_stats["n_pairs_bbox"])
-        self.max_pairs = int(min(0xFFFFFFF0, max(4096, slack * need + 4096)))
+        self.max_pairs = int(min(_lib.GSR_MAX_PAIRS, max(4096, slack * need + 4096)))
         return self.max_pairs
 
     # -- stage-by-stage (tests, helper functions) -------------------------------------------------
