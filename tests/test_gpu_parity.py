@@ -533,31 +533,3 @@ def test_depth_sort_plans_its_passes_from_the_key_range(G):
     assert_frames_close(fimg, foimg)
     # the plan is per frame: the near scene on the far scene's workspace geometry goes back to 3 passes
     assert torch.equal(R.render(cam), torch.from_numpy(img).to("cuda")) and _ctrl_word(R, cam, SORT_PASSES_OFFSET) == 3
-
-
-@pytest.mark.parametrize("name,prefix", [("medium", ""), ("f3_edge.npz", "a_"), ("f3_edge.npz", "b_")])
-def test_fused_binning_equals_the_emit_then_sort_path(G, monkeypatch, name, prefix):
-    """binning.hip: generating the pairs inside the first tile-sort pass (fused path) must give the very lists the legacy
-    path builds (emit in depth order, then the generic sort over all key bits): identical frames, T and counters —
-    whole frame, shards, progressive prefixes, a frame-covering gaussian (f3a), a frame not a multiple of 16 (f3b)."""
-    if name == "medium":
-        cols, cam, _ = _medium(G, n=150_000)
-    else:
-        g = load_golden(name)
-        cols = golden_columns(g)
-        cam, _ = _cams(G, g, prefix)
-    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
-    mk = G.renderer.make_options
-    variants = [mk(), mk(tile_row_begin=1, tile_row_step=3, output_layout=2), mk(draw_limit=37), mk(no_footprint_cull=True)]
-    fused = []
-    for o in variants:
-        img, T = R.render(cam, o, return_T=True)
-        fused.append((img.clone(), T.clone(), dict(R.last_stats)))
-    monkeypatch.setenv("GSR_LEGACY_BINNING", "1")
-    for o, (img, T, st) in zip(variants, fused):
-        limg, lT = R.render(cam, o, return_T=True)
-        assert torch.equal(limg, img) and torch.equal(lT, T)
-        for k in ("n_visible", "n_pairs", "n_pairs_bbox", "max_list_len", "fetched_entries", "wave_entries"):
-            assert R.last_stats[k] == st[k], k
-    monkeypatch.delenv("GSR_LEGACY_BINNING")
-    assert torch.equal(R.render(cam), fused[0][0])

@@ -42,10 +42,9 @@ size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max
     ws->max_pairs = max_pairs;
     ws->tiles_x = (width + GSR_TILE - 1) / GSR_TILE;
     ws->tiles_y = (height + GSR_TILE - 1) / GSR_TILE;
-    // row stride of the histogram table: tiles of the depth sort, tiles of the pair sort, gaussian blocks of the fused binning
-    ws->hist_blocks = (int)std::max({(nn + SORT_THREADS * DEPTH_SORT_ITEMS - 1) / (SORT_THREADS * DEPTH_SORT_ITEMS),
-                                     (np + SORT_THREADS * PAIR_SORT_ITEMS - 1) / (SORT_THREADS * PAIR_SORT_ITEMS),
-                                     (nn + PAIR_BLOCK - 1) / PAIR_BLOCK});
+    // row stride of the histogram table: tiles of the depth sort, tiles of the pair sort
+    ws->hist_blocks = (int)std::max((nn + DEPTH_SORT_THREADS * DEPTH_SORT_ITEMS - 1) / (DEPTH_SORT_THREADS * DEPTH_SORT_ITEMS),
+                                    (np + PAIR_SORT_THREADS * PAIR_SORT_ITEMS - 1) / (PAIR_SORT_THREADS * PAIR_SORT_ITEMS));
     ws->ctrl = static_cast<FrameCtrl *>(take(sizeof(FrameCtrl)));
     ws->rec = static_cast<GaussRec *>(take(sizeof(GaussRec) * nn));
     ws->rect = static_cast<ushort4 *>(take(sizeof(ushort4) * nn));

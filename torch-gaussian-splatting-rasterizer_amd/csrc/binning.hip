@@ -4,37 +4,31 @@
 // (rasterize.py:440-446); here each visible gaussian is expanded into the 16x16 tiles
 // (BLOCK_SIZE, rasterize.py:34) of its rect so that tiles can be composited independently.
 //
-// Pair key = (tile row << bits_x) | tile column; a pair that footprint culling rejects keeps its column and takes the
-// row `tiles_y` (one past the last), so that it still owns the slot the counting pass gave it and is dropped by the
-// sort pass over the row bits.  Stable sort by column, then by row => per-tile lists in depth order.
+// Pair key = (tile row << bits_x) | tile column; a pair that footprint culling rejects takes the row `tiles_y` (one past
+// the last) and is dropped by the first pass of the tile sort.
 //
-// FUSED PATH (frames up to 4096 px, i.e. <= 256 tile columns and < 256 tile rows): pairs are never written in emission
-// order.  The first radix pass of the tile sort (digit = tile column) is folded into pair generation:
-//   pair_hist      one workgroup per block of PAIR_BLOCK depth-sorted gaussians (rects arrive packed, coalesced, as the
-//                  depth sort's second payload): for every gaussian, +rows into every column of its rect (LDS atomics)
-//                  -> hist[column][block].  This IS the pass-0 histogram; no pair is generated for it.
-//   rowscan        (sort.hip) exclusive scan of every column's row, column totals -> digit_tot
-//   pair_scatter0  same blocks: the block's pairs are generated 4096 at a time in emission order (slot -> owning gaussian
-//                  by binary search over the block's offsets in LDS, -> row/column inside its rect), ranked and reordered
-//                  by column with the machinery of the radix scatter (radix.h) and written straight to their
-//                  column-sorted positions.  A block holding a frame-covering gaussian simply takes more rounds.
-//                  Rects above CULL_MIN_TILES tiles are tested tile by tile against the gaussian's alpha > 1/255
-//                  footprint (footprint.h); smaller rects skip the test (the blend culls per 8x8 quadrant anyway).
-//                  Workgroup 0 also totals D = sum of the column totals: overflow flag, slots = min(D, max_pairs).
-//   then one ordinary radix pass over the row bits (sort.hip) and
-//   ranges         boundaries of equal keys in the sorted pair array -> ranges[tile] = [begin, end)
-// Against emit + a separate pass 0 this removes the emit kernel, the pass-0 histogram kernel, the block-offset scan, and
-// one write + two reads of the pair arrays.
-//
-// LEGACY PATH (wider frames; GSR_LEGACY_BINNING=1 forces it for A/B timing): count -> scan -> emit in emission order,
-// then the generic sort over all key bits.
+//   count   one thread per depth-sorted gaussian: tiles of its rect that belong to this shard
+//           (tile rows begin, begin+step, ...) -> per-workgroup sums.  The rect arrives packed in the depth
+//           sort's second payload (coalesced); frames wider than 4096 px gather it by gaussian id instead.
+//   scan    one workgroup: exclusive scan of the workgroup sums; D, overflow flag, slots = min(D, max_pairs)
+//   emit    load-balanced expansion: a workgroup owns 256 consecutive gaussians and the contiguous slot range
+//           their pairs occupy; every thread takes slots j, j+256, ..., finds the owning gaussian by binary
+//           search over the workgroup's 256 offsets in LDS and writes (tile key, gaussian id) — coalesced stores,
+//           no divergence however heavy-tailed the rect sizes are (median 4 tiles, max thousands).
+//           Rects above CULL_MIN_TILES tiles are tested tile by tile against the gaussian's alpha > 1/255
+//           footprint (footprint.h): unreachable tiles (corners of oblique ellipses) are marked culled.
+//           Smaller rects skip the test (it needs a 32-B gather per gaussian; the blend culls per 8x8 quadrant anyway).
+//   sort    (sort.hip) stable radix sort by tile key, 2 passes for frames up to 4096 px
+//   ranges  boundaries of equal keys in the tile-sorted pair array -> ranges[tile] = [begin, end)
+// Measured and rejected (round 2): generating the pairs INSIDE the first tile-sort pass (a histogram of rows-per-column
+// per block of 768 gaussians, then generate + rank + reorder 4096 pairs per round): it removes the emit kernel, a
+// histogram kernel and one write + two reads of the pair arrays, but a workgroup then walks its rounds serially with
+// rounds 69 % full and 3 instead of 4 workgroups per CU — 245 us against 149 us for emit + histogram + scatter.
 // Roofline: HBM.  Bytes: 8 B per sorted gaussian (id + rect) + 8 B per pair written; ranges reads 4 B per pair.
-#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include "gsr_internal.h"
 #include "footprint.h"
-#include "radix.h"
 
 namespace gsr {
 
@@ -82,178 +76,6 @@ __device__ __forceinline__ void row_col(uint32_t k, uint32_t w, uint32_t *row, u
     *row = r;
     *col = k - r * w;
 }
-
-// ============================================ fused path =====================================================
-
-__global__ __launch_bounds__(EMIT_THREADS) void pair_hist_kernel(const uint32_t *__restrict__ r8_a, const uint32_t *__restrict__ r8_b,
-                                                                 const FrameCtrl *ctrl, Shard sh, uint32_t *__restrict__ hist,
-                                                                 int hist_blocks, uint2 *__restrict__ ranges, int n_tiles,
-                                                                 uint32_t grid_threads, uint32_t draw_limit)
-{
-    __shared__ uint32_t colh[256];
-    const int tid = threadIdx.x;
-    for (uint32_t t = blockIdx.x * EMIT_THREADS + tid; t < (uint32_t)n_tiles; t += grid_threads) ranges[t] = make_uint2(0u, 0u);  // rebuilt every frame
-    const uint32_t n = ctrl->n_visible;
-    const uint32_t gbase = blockIdx.x * (uint32_t)PAIR_BLOCK;
-    if (gbase >= n) return;  // uniform; the rowscan stops at the live blocks too
-    const uint32_t *__restrict__ r8 = (ctrl->sort_passes & 1u) ? r8_b : r8_a;  // where the depth sort left its result
-    colh[tid] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < PAIR_BLOCK / EMIT_THREADS; ++k) {
-        const uint32_t r = gbase + k * EMIT_THREADS + tid;  // rank in the draw order
-        if (r < n && r < draw_limit) {
-            const ushort4 rc = unpack_rect8(r8[r]);
-            int first, rows;
-            shard_rows(rc.y, rc.w, sh, &first, &rows);
-            if (rows > 0)
-                for (int tx = rc.x; tx < rc.z; ++tx) atomicAdd(&colh[tx], (uint32_t)rows);
-        }
-    }
-    __syncthreads();
-    hist[(size_t)tid * hist_blocks + blockIdx.x] = colh[tid];
-}
-
-__global__ __launch_bounds__(EMIT_THREADS) void pair_scatter0_kernel(const uint32_t *__restrict__ id_a, const uint32_t *__restrict__ id_b,
-                                                                     const uint32_t *__restrict__ r8_a, const uint32_t *__restrict__ r8_b,
-                                                                     FrameCtrl *ctrl, Shard sh, int bits_x, int tiles_y,
-                                                                     const GaussRec *__restrict__ rec, const uint32_t *__restrict__ hist,
-                                                                     int hist_blocks, uint32_t max_pairs, uint32_t *__restrict__ pkey,
-                                                                     uint32_t *__restrict__ pval, uint32_t draw_limit)
-{
-    using Smem = RadixTileSmem<256, PAIR_SORT_ITEMS, false>;
-    constexpr int ITEMS = PAIR_SORT_ITEMS, TILE = Smem::TILE, PER = PAIR_BLOCK / EMIT_THREADS;
-    __shared__ Smem sm;
-    __shared__ uint32_t s_off[PAIR_BLOCK + 1];  // exclusive pair offset of each gaussian inside the block
-    __shared__ uint32_t s_id[PAIR_BLOCK];
-    __shared__ uint32_t s_r8[PAIR_BLOCK];
-    __shared__ unsigned long long s_base[256];  // next global position of column d for this block (64-bit: D may pass 2^32)
-    __shared__ unsigned long long s_wsum[4];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t n = ctrl->n_visible;
-    const uint32_t gbase = blockIdx.x * (uint32_t)PAIR_BLOCK;
-    if (gbase >= n && blockIdx.x != 0) return;  // uniform.  Workgroup 0 always runs: it publishes D
-    const bool odd = (ctrl->sort_passes & 1u) != 0;
-    const uint32_t *__restrict__ ids = odd ? id_b : id_a;
-    const uint32_t *__restrict__ r8 = odd ? r8_b : r8_a;
-
-    // ---- this block's gaussians (thread t owns PER consecutive ones), their pair counts and offsets -------------
-    uint32_t cnt[PER], mine = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int i = tid * PER + k;
-        const uint32_t r = gbase + i;
-        uint32_t g = 0, packed = 1u;  // packed {x0 = 1, x1 - 1 = 0}: zero width
-        cnt[k] = 0;
-        if (r < n && r < draw_limit) {
-            g = ids[r];
-            packed = r8[r];
-            int first;
-            cnt[k] = tiles_of(unpack_rect8(packed), sh, &first);
-        }
-        s_id[i] = g;
-        s_r8[i] = packed;
-        mine += cnt[k];
-    }
-    uint32_t total;
-    {
-        uint32_t ex = block_excl_scan_256(mine, sm.scratch, &total);
-#pragma unroll
-        for (int k = 0; k < PER; ++k) { s_off[tid * PER + k] = ex; ex += cnt[k]; }
-        if (tid == 0) s_off[PAIR_BLOCK] = total;
-    }
-    // ---- global start of every column for this block: scan of the column totals (64-bit) + the scanned histogram -----
-    {
-        const unsigned long long tot = ctrl->digit_tot[tid];
-        unsigned long long incl = tot;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        if (lane == 63) s_wsum[wave] = incl;
-        __syncthreads();
-        unsigned long long wbase = 0, D = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const unsigned long long sw = s_wsum[w];
-            if (w < wave) wbase += sw;
-            D += sw;
-        }
-        s_base[tid] = wbase + (incl - tot) + (gbase < n ? hist[(size_t)tid * hist_blocks + blockIdx.x] : 0u);
-        if (blockIdx.x == 0 && tid == 0) {
-            const uint32_t Dc = D > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)D;
-            // batch_overflow / batch_need survive the per-frame clear inside gsr_render_batch: an overflow in any view of
-            // a batch stays visible in the counters of the last one, together with the largest D of the batch
-            if (D > (unsigned long long)max_pairs) { ctrl->batch_overflow = 1u; ctrl->batch_need = max(ctrl->batch_need, Dc); }
-            ctrl->overflow = ctrl->batch_overflow;
-            ctrl->n_pairs_bbox = ctrl->batch_overflow ? max(ctrl->batch_need, Dc) : Dc;
-            ctrl->n_slots = D > (unsigned long long)max_pairs ? max_pairs : (uint32_t)D;
-        }
-    }
-    if (gbase >= n) return;  // workgroup 0 of an empty frame
-    const uint32_t maskx = (1u << bits_x) - 1u;
-    const uint32_t culled_row = (uint32_t)tiles_y << bits_x;
-
-    // ---- rounds of TILE pairs in emission order ------------------------------------------------------------------
-    for (uint32_t round = 0; round < total; round += TILE) {
-        __syncthreads();  // s_off / s_base ready (first round); previous round's LDS tile fully written out (later rounds)
-        radix_clear(sm);
-        __syncthreads();
-        uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
-        const uint32_t dummy[1] = {0u};
-#pragma unroll
-        for (int r = 0; r < ITEMS; ++r) {
-            const uint32_t j = round + wave * (64 * ITEMS) + r * 64 + lane;
-            key[r] = KEY_INVALID;
-            val[r] = 0u;
-            if (j < total) {
-                // owner = last gaussian whose offset is <= j (zero-count gaussians share an offset with their successor)
-                int lo = 0;
-#pragma unroll
-                for (int step = 512; step >= 1; step >>= 1)
-                    if (lo + step < PAIR_BLOCK && s_off[lo + step] <= j) lo += step;
-                const uint32_t k = j - s_off[lo];
-                const ushort4 rc = unpack_rect8(s_r8[lo]);
-                uint32_t row, col;
-                row_col(k, (uint32_t)(rc.z - rc.x), &row, &col);
-                int first, rows;
-                shard_rows(rc.y, rc.w, sh, &first, &rows);
-                const int ty = first + (int)row * sh.step, tx = (int)rc.x + (int)col;
-                const uint32_t g = s_id[lo];
-                bool hit = true;
-                if ((uint32_t)rows * (uint32_t)(rc.z - rc.x) > CULL_MIN_TILES)
-                    hit = footprint_hits_rect(rec[g].q0, rec[g].q1, (float)(tx * 16), (float)(tx * 16 + 15), (float)(ty * 16),
-                                              (float)(ty * 16 + 15));
-                key[r] = (hit ? (uint32_t)ty << bits_x : culled_row) | (uint32_t)tx;
-                val[r] = g;
-            }
-        }
-        auto dig = [&](int r) -> uint32_t { return key[r] == KEY_INVALID ? RADIX_NO_DIGIT : key[r] & maskx; };
-        radix_rank(sm, dig, rank);
-        __syncthreads();
-        uint32_t dcnt[1];
-        radix_tile_layout(sm, dcnt);
-        __syncthreads();
-        radix_reorder(sm, dig, rank, key, val, dummy);
-        __syncthreads();
-        const uint32_t nvalid = sm.n_valid;
-        for (uint32_t i = tid; i < nvalid; i += EMIT_THREADS) {
-            const uint32_t kk = sm.skey[i];
-            const uint32_t d = kk & maskx;
-            const unsigned long long gpos = s_base[d] + (i - sm.tile_start[d]);
-            if (gpos < (unsigned long long)max_pairs) {
-                pkey[gpos] = kk;
-                pval[gpos] = sm.sval[i];
-            }
-        }
-        __syncthreads();
-        s_base[tid] += dcnt[0];  // thread t owns column t
-    }
-}
-
-// ============================================ legacy path ====================================================
 
 template <bool PACKED>
 __device__ __forceinline__ ushort4 rect_of(uint32_t r, const uint32_t *sorted_ids, const uint32_t *sorted_rect8, const ushort4 *rect)
@@ -420,8 +242,6 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
     }
 }
 
-// ============================================ tile ranges =====================================================
-
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t *__restrict__ pkey, const FrameCtrl *ctrl,
                                                           uint2 *__restrict__ ranges, int bits_x, int tiles_x, int n_tiles,
                                                           uint32_t stride)
@@ -467,11 +287,6 @@ TileKeying tile_keying(const Workspace &ws)
     k.bits_x = std::max(1, ceil_log2(ws.tiles_x));
     k.bits_y = std::max(1, ceil_log2(ws.tiles_y + 1));  // one spare row value marks culled pairs
     k.drop_from = (uint32_t)ws.tiles_y << k.bits_x;
-    k.fused = rect_fits_8bit(ws) && k.bits_x <= 8 && k.bits_y <= 8;
-    if (k.fused) {
-        const char *e = std::getenv("GSR_LEGACY_BINNING");
-        if (e && e[0] == '1') k.fused = false;
-    }
     return k;
 }
 
@@ -480,8 +295,7 @@ int pair_result_buf(const Workspace &ws)
 {
     if (ws.n <= 0 || ws.max_pairs <= 0) return 0;
     const TileKeying tk = tile_keying(ws);
-    if (tk.fused) return 1 ^ (((tk.bits_y + 7) / 8) & 1);  // generated into buffer 1, then the passes over the row bits
-    return ((tk.bits_x + tk.bits_y + 7) / 8) & 1;
+    return ((tk.bits_x + tk.bits_y + 7) / 8) & 1;  // ping-pong parity of the tile sort's passes
 }
 
 int launch_binning(const GsrOptions &opts, const Workspace &ws, int *pair_buf, hipStream_t s)
@@ -494,18 +308,6 @@ int launch_binning(const GsrOptions &opts, const Workspace &ws, int *pair_buf, h
     const TileKeying tk = tile_keying(ws);
     const uint32_t cap = (uint32_t)ws.max_pairs;
     const uint32_t limit = opts.draw_limit > 0 ? (uint32_t)opts.draw_limit : 0xFFFFFFFFu;
-    if (tk.fused) {
-        const int nblk = (int)((ws.n + PAIR_BLOCK - 1) / PAIR_BLOCK);
-        if (nblk > ws.hist_blocks) { set_error("binning: %d blocks exceed the histogram stride %d", nblk, ws.hist_blocks); return GSR_ERR_WORKSPACE; }
-        hipLaunchKernelGGL(pair_hist_kernel, dim3(nblk), dim3(EMIT_THREADS), 0, s, ws.rect8[0], ws.rect8[1], ws.ctrl, sh, ws.hist,
-                           ws.hist_blocks, ws.ranges, n_tiles, (uint32_t)nblk * EMIT_THREADS, limit);
-        launch_rowscan_blocks(ws, 256, PAIR_BLOCK, &ws.ctrl->n_visible, ws.n, s);  // all 256 rows: the scatter scans digit_tot[0..256)
-        hipLaunchKernelGGL(pair_scatter0_kernel, dim3(nblk), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1],
-                           ws.ctrl, sh, tk.bits_x, ws.tiles_y, ws.rec, ws.hist, ws.hist_blocks, cap, ws.pkey[1], ws.pval[1], limit);
-        GSR_HIP(hipGetLastError());
-        // second pass: the row bits; drops the culled pairs (row == tiles_y) and leaves E in ctrl
-        return launch_pair_sort(ws, 1, &ws.ctrl->n_slots, tk.bits_x, tk.bits_x + tk.bits_y, tk.drop_from, &ws.ctrl->n_pairs, pair_buf, s);
-    }
     // the count kernel also zeroes ranges[]: make sure its grid covers them
     const int nblk = (int)((std::max<int64_t>(ws.n, n_tiles) + EMIT_THREADS - 1) / EMIT_THREADS);
     const int nblk_n = (int)((ws.n + EMIT_THREADS - 1) / EMIT_THREADS);

@@ -45,15 +45,11 @@ struct alignas(16) GaussRec {
     float4 q0, q1, q2;
 };
 
-constexpr int SORT_THREADS = 256;
-constexpr int DEPTH_SORT_ITEMS = 16;  // keys per thread per pass (2048-key tiles measured slower: fixed per-workgroup costs dominate)
+constexpr int DEPTH_SORT_THREADS = 512;  // depth sort: 9-bit digits on 8192-key tiles (radix.h)
+constexpr int PAIR_SORT_THREADS = 256;   // pair sort: <= 8-bit digits on 4096-pair tiles
+constexpr int DEPTH_SORT_ITEMS = 16;     // keys per thread per pass (2048-key tiles measured slower: fixed per-workgroup costs dominate)
 constexpr int PAIR_SORT_ITEMS = 16;
 constexpr int EMIT_THREADS = 256;                     // threads per workgroup in the binning kernels
-#ifndef GSR_PAIR_BLOCK
-#define GSR_PAIR_BLOCK 768
-#endif
-constexpr int PAIR_BLOCK = GSR_PAIR_BLOCK;            // gaussians per workgroup of the fused binning path: ~3.6 k pairs on a full-HD frame = one round of 4096
-static_assert(PAIR_BLOCK % EMIT_THREADS == 0 && PAIR_BLOCK <= 1024, "whole gaussians per thread; the owner search takes 10 steps");
 constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
 
 struct Workspace {
@@ -111,14 +107,10 @@ int launch_depth_sort(const Workspace &ws, bool packed_rect, hipStream_t s);
 // survivor count in *n_out.  in_buf / *result_buf: which of pkey[]/pval[] holds input / output.
 int launch_pair_sort(const Workspace &ws, int in_buf, const uint32_t *n_dev, int first_bit, int key_bits, uint32_t drop_from,
                      uint32_t *n_out, int *result_buf, hipStream_t s);
-// Exclusive scan of hist rows [0, rows) over the live blocks (blocks of `block` elements, element count *n_dev) -> digit_tot.
-void launch_rowscan_blocks(const Workspace &ws, int rows, int block, const uint32_t *n_dev, int64_t n_bound, hipStream_t s);
-
 // Pair keys: (tile row << bits_x) | tile column; culled pairs carry the row `tiles_y` and are dropped from drop_from on.
 struct TileKeying {
     int bits_x, bits_y;
     uint32_t drop_from;
-    bool fused;  // first tile-sort pass fused with pair generation (binning.hip)
 };
 TileKeying tile_keying(const Workspace &ws);
 inline bool rect_fits_8bit(const Workspace &ws) { return ws.tiles_x <= 256 && ws.tiles_y <= 256; }
@@ -152,6 +144,28 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *sc
     uint32_t base = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
+        const uint32_t s = scratch[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+
+// The same for THREADS = 64 * WAVES threads; `scratch` = 2 * WAVES uint32 of LDS.
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *scratch, uint32_t *total)
+{
+    constexpr int WAVES = THREADS / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan(v);
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
         const uint32_t s = scratch[w];
         if (w < wave) base += s;
         tot += s;

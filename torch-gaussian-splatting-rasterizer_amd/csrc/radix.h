@@ -1,8 +1,7 @@
-// radix.h — workgroup-level building blocks of the stable LSD radix passes (sort.hip) and of the fused
-// pair-generation + first tile pass (binning.hip).  No reference counterpart: the reference orders gaussians with one
-// torch.sort (rasterize.py:424-425) and has no tile lists.
+// radix.h — workgroup-level building blocks of the stable LSD radix passes (sort.hip).  No reference counterpart: the
+// reference orders gaussians with one torch.sort (rasterize.py:424-425) and has no tile lists.
 //
-// A pass handles a tile of 256 * ITEMS records per workgroup; wave w owns items [w*64*ITEMS, (w+1)*64*ITEMS) in ITEMS
+// A pass handles a tile of THREADS * ITEMS records per workgroup; wave w owns items [w*64*ITEMS, (w+1)*64*ITEMS) in ITEMS
 // rounds of 64 consecutive records, so tile order == (wave, round, lane) order — what keeps every pass stable.
 //   radix_clear        zero the per-wave digit counters and the peer masks
 //   radix_rank         rank[r] = number of EARLIER records of this wave with the same digit (through LDS peer masks)
@@ -43,29 +42,34 @@ __device__ __forceinline__ bool resolve_pass(const PassSpec &a, const FrameCtrl 
     return true;
 }
 
-template <int DIGITS, int ITEMS, bool HAS_V2>
+// One workgroup of THREADS threads sorts a tile of THREADS * ITEMS records on a digit of up to log2(THREADS) bits: thread t
+// owns digit t in the per-digit steps.  256 threads / 4096 records for the pair sort (8-bit digits and fewer), 512 threads /
+// 8192 records for the depth sort's 9-bit digits: with twice the digit values a 4096-record tile's runs halve (8 records =
+// 32 B per array, measured +35 % per pass); doubling the tile keeps the runs at 16 records and the table reads per record equal.
+template <int THREADS, int ITEMS, bool HAS_V2>
 struct RadixTileSmem {
-    static constexpr int TILE = SORT_THREADS * ITEMS;
-    static_assert(DIGITS == 256 || DIGITS == 512, "one or two digits per thread");
-    static_assert(4 * DIGITS * 8 <= TILE * 4, "the peer masks live in skey until the reorder");
-    uint32_t wave_cnt[4][DIGITS];  // per-wave digit counts, then per-wave exclusive bases
-    uint32_t tile_start[DIGITS];   // start of digit d inside the reordered tile
+    static constexpr int TILE = THREADS * ITEMS, WAVES = THREADS / 64, DIGITS = THREADS;
+    static_assert(THREADS == 256 || THREADS == 512, "digit d is owned by thread d");
+    static_assert(WAVES * DIGITS * 8 <= TILE * 4, "the peer masks live in skey until the reorder");
+    uint32_t wave_cnt[WAVES][DIGITS];  // per-wave digit counts, then per-wave exclusive bases
+    uint32_t tile_start[DIGITS];       // start of digit d inside the reordered tile
     uint32_t skey[TILE];
     uint32_t sval[TILE];
     uint32_t sval2[HAS_V2 ? TILE : 1];
-    uint32_t scratch[8];
+    uint32_t scratch[2 * WAVES];
     uint32_t n_valid;
 };
 
-template <int DIGITS, int ITEMS, bool HAS_V2>
-__device__ __forceinline__ void radix_clear(RadixTileSmem<DIGITS, ITEMS, HAS_V2> &sm)
+template <int THREADS, int ITEMS, bool HAS_V2>
+__device__ __forceinline__ void radix_clear(RadixTileSmem<THREADS, ITEMS, HAS_V2> &sm)
 {
+    constexpr int WAVES = THREADS / 64;
     uint32_t *wc = &sm.wave_cnt[0][0];
     unsigned long long *pm = reinterpret_cast<unsigned long long *>(sm.skey);
 #pragma unroll
-    for (int i = 0; i < 4 * DIGITS / SORT_THREADS; ++i) {
-        wc[i * SORT_THREADS + threadIdx.x] = 0u;
-        pm[i * SORT_THREADS + threadIdx.x] = 0ull;
+    for (int i = 0; i < WAVES; ++i) {
+        wc[i * THREADS + threadIdx.x] = 0u;
+        pm[i * THREADS + threadIdx.x] = 0ull;
     }
 }
 
@@ -76,11 +80,11 @@ __device__ __forceinline__ void radix_clear(RadixTileSmem<DIGITS, ITEMS, HAS_V2>
 // eight ballots per round with a per-lane 64-bit select after each, measured 8 us of the scatter kernel's 17 us per
 // workgroup: ~50 VALU instructions per round.)  The lowest lane of each group then advances the wave's running count of
 // that digit and hands the old value to its peers.  dig(r) returns the digit of this thread's r-th record or RADIX_NO_DIGIT.
-template <int DIGITS, int ITEMS, bool HAS_V2, typename DigitOf>
-__device__ __forceinline__ void radix_rank(RadixTileSmem<DIGITS, ITEMS, HAS_V2> &sm, DigitOf dig, uint32_t (&rank)[ITEMS])
+template <int THREADS, int ITEMS, bool HAS_V2, typename DigitOf>
+__device__ __forceinline__ void radix_rank(RadixTileSmem<THREADS, ITEMS, HAS_V2> &sm, DigitOf dig, uint32_t (&rank)[ITEMS])
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long *pm = reinterpret_cast<unsigned long long *>(sm.skey) + wave * DIGITS;  // skey is not live until the reorder
+    unsigned long long *pm = reinterpret_cast<unsigned long long *>(sm.skey) + wave * THREADS;  // skey is not live until the reorder
     uint32_t *wc = sm.wave_cnt[wave];
     const unsigned long long my_bit = 1ull << lane, lt_mask = my_bit - 1ull;
     // GROUP rounds at a time: all their LDS traffic is issued back to back (three waits per group instead of per round)
@@ -116,40 +120,29 @@ __device__ __forceinline__ void radix_rank(RadixTileSmem<DIGITS, ITEMS, HAS_V2> 
     }
 }
 
-// After radix_rank + a barrier.  Thread t owns the digits DPT*t .. DPT*t + DPT - 1 (DPT = DIGITS / 256): turns the
-// per-wave counts into per-wave exclusive bases, fills tile_start[], leaves the tile's record count in sm.n_valid and
-// this thread's per-digit counts in cnt[].  Contains two barriers; the caller adds one before using the tables.
-template <int DIGITS, int ITEMS, bool HAS_V2>
-__device__ __forceinline__ void radix_tile_layout(RadixTileSmem<DIGITS, ITEMS, HAS_V2> &sm, uint32_t (&cnt)[DIGITS / SORT_THREADS])
+// After radix_rank + a barrier.  Thread t owns digit t: turns the per-wave counts into per-wave exclusive bases, fills
+// tile_start[], leaves the tile's record count in sm.n_valid.  Contains two barriers; the caller adds one before using
+// the tables.
+template <int THREADS, int ITEMS, bool HAS_V2>
+__device__ __forceinline__ void radix_tile_layout(RadixTileSmem<THREADS, ITEMS, HAS_V2> &sm)
 {
-    constexpr int DPT = DIGITS / SORT_THREADS;
-    const int d0 = DPT * threadIdx.x;
-    uint32_t c[4][DPT], mine = 0;
+    constexpr int WAVES = THREADS / 64;
+    const int d = threadIdx.x;
+    uint32_t c[WAVES], cnt = 0;
 #pragma unroll
-    for (int j = 0; j < DPT; ++j) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) c[w][j] = sm.wave_cnt[w][d0 + j];
-        cnt[j] = c[0][j] + c[1][j] + c[2][j] + c[3][j];
-        mine += cnt[j];
-    }
+    for (int w = 0; w < WAVES; ++w) { c[w] = sm.wave_cnt[w][d]; cnt += c[w]; }
     uint32_t total;
-    uint32_t ex = block_excl_scan_256(mine, sm.scratch, &total);
+    sm.tile_start[d] = block_excl_scan<THREADS>(cnt, sm.scratch, &total);
+    uint32_t run = 0;
 #pragma unroll
-    for (int j = 0; j < DPT; ++j) {
-        sm.tile_start[d0 + j] = ex;
-        ex += cnt[j];
-        sm.wave_cnt[0][d0 + j] = 0;
-        sm.wave_cnt[1][d0 + j] = c[0][j];
-        sm.wave_cnt[2][d0 + j] = c[0][j] + c[1][j];
-        sm.wave_cnt[3][d0 + j] = c[0][j] + c[1][j] + c[2][j];
-    }
+    for (int w = 0; w < WAVES; ++w) { sm.wave_cnt[w][d] = run; run += c[w]; }
     if (threadIdx.x == 0) sm.n_valid = total;
 }
 
 // Records -> LDS in digit order (stable).  Needs the tables of radix_tile_layout behind a barrier; the caller adds a
 // barrier before reading skey/sval back.
-template <int DIGITS, int ITEMS, bool HAS_V2, typename DigitOf>
-__device__ __forceinline__ void radix_reorder(RadixTileSmem<DIGITS, ITEMS, HAS_V2> &sm, DigitOf dig, const uint32_t (&rank)[ITEMS],
+template <int THREADS, int ITEMS, bool HAS_V2, typename DigitOf>
+__device__ __forceinline__ void radix_reorder(RadixTileSmem<THREADS, ITEMS, HAS_V2> &sm, DigitOf dig, const uint32_t (&rank)[ITEMS],
                                               const uint32_t (&key)[ITEMS], const uint32_t (&val)[ITEMS],
                                               const uint32_t (&val2)[HAS_V2 ? ITEMS : 1])
 {

@@ -5,8 +5,7 @@
 //      by pass 0), values = gaussian id (+ its packed tile rect).  Stable from index order => depth ties
 //      resolve by gaussian index.
 //   2. tile lists:   keys = (tile row, tile column) of every (gaussian,tile) pair emitted IN DEPTH ORDER, values = gaussian
-//      id.  A stable sort by tile therefore leaves every tile's list depth-ordered.  (Frames up to 4096 px: the first
-//      of its two passes is fused with pair generation in binning.hip; this file runs the second.)
+//      id.  A stable sort by tile therefore leaves every tile's list depth-ordered.
 //
 // Per pass, three launches (no inter-workgroup hand-off inside a launch, so nothing depends on dispatch
 // order or XCD placement; a dependent kernel boundary costs ~1.5 us, an in-kernel grid barrier 4-10 us):
@@ -15,7 +14,8 @@
 //   scatter  one workgroup per tile: per-wave ranking through LDS peer masks -> tile reordered by digit in LDS -> digit
 //            runs written out contiguously (coalesced), position = digit base + scanned hist + rank in run   (radix.h)
 // The element count lives in device memory (n_dev): grids are sized by the host-side bound and surplus workgroups fall
-// through.  4096-key tiles (16 keys per thread): 2048-key tiles measured slower, the fixed per-workgroup costs dominate.
+// through.  16 keys per thread (2048-key tiles measured slower, the fixed per-workgroup costs dominate); the depth sort's
+// 9-bit passes run 512 threads on 8192 keys, the pair sort's <= 8-bit passes 256 threads on 4096 (radix.h says why).
 //
 // Depth sort in three passes instead of four.  z_cam >= 0.2, so a key's sign and high exponent bits never vary: the sort
 // runs on key - bits(0.2f), and only on the bits the frame actually uses.  Pass 0 always takes 9 bits; its histogram
@@ -38,13 +38,13 @@ __device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t n
     return n < n_bound ? n : n_bound;
 }
 
-template <int DIGITS, bool DROP, int ITEMS>
-__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t *__restrict__ keys, const uint32_t *n_dev,
-                                                                  uint32_t n_bound, PassSpec ps, FrameCtrl *ctrl,
-                                                                  uint32_t *__restrict__ hist, int hist_blocks)
+template <int THREADS, bool DROP, int ITEMS>
+__global__ __launch_bounds__(THREADS) void radix_hist_kernel(const uint32_t *__restrict__ keys, const uint32_t *n_dev,
+                                                             uint32_t n_bound, PassSpec ps, FrameCtrl *ctrl,
+                                                             uint32_t *__restrict__ hist, int hist_blocks)
 {
-    constexpr int TILE = SORT_THREADS * ITEMS;
-    __shared__ uint32_t h[DIGITS];
+    constexpr int TILE = THREADS * ITEMS;
+    __shared__ uint32_t h[THREADS];
     __shared__ uint32_t s_max;
     int shift;
     uint32_t mask;
@@ -52,15 +52,14 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
     const uint32_t n = load_count(n_dev, n_bound);
     const uint32_t base = blockIdx.x * (uint32_t)TILE;
     if (base >= n) return;  // rowscan and scatter stop at the live tiles too
-#pragma unroll
-    for (int j = 0; j < DIGITS / SORT_THREADS; ++j) h[j * SORT_THREADS + threadIdx.x] = 0;
+    h[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_max = 0;
     __syncthreads();
     uint32_t kmax = 0;
     if (n - base >= (uint32_t)TILE) {  // full tile: unguarded loads, all in flight together
         uint32_t k[ITEMS];
 #pragma unroll
-        for (int r = 0; r < ITEMS; ++r) k[r] = keys[base + r * SORT_THREADS + threadIdx.x];
+        for (int r = 0; r < ITEMS; ++r) k[r] = keys[base + r * THREADS + threadIdx.x];
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r)
             if (!DROP || k[r] < ps.drop_from) {
@@ -70,7 +69,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
     } else {
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
-            const uint32_t idx = base + r * SORT_THREADS + threadIdx.x;
+            const uint32_t idx = base + r * THREADS + threadIdx.x;
             if (idx < n) {
                 const uint32_t k = keys[idx];
                 if (!DROP || k < ps.drop_from) {
@@ -86,11 +85,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
         if ((threadIdx.x & 63) == 0) atomicMax(&s_max, kmax);
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < DIGITS / SORT_THREADS; ++j) {
-        const int d = j * SORT_THREADS + threadIdx.x;
-        hist[(size_t)d * hist_blocks + blockIdx.x] = h[d];
-    }
+    hist[(size_t)threadIdx.x * hist_blocks + blockIdx.x] = h[threadIdx.x];
     if (ps.dyn_pass == 0 && threadIdx.x == 0) {
         const uint32_t m = s_max;
         // the running maximum only grows: a stale (smaller) value read here costs one redundant atomic, never a wrong result
@@ -104,7 +99,7 @@ template <int TILE>
 __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t *__restrict__ hist, int hist_blocks, const uint32_t *n_dev,
                                                             uint32_t n_bound, PassSpec ps, FrameCtrl *ctrl)
 {
-    __shared__ unsigned long long wsum[4];
+    __shared__ uint32_t scratch[8];
     int shift;
     uint32_t mask;
     if (!resolve_pass(ps, ctrl, &shift, &mask)) return;
@@ -122,54 +117,35 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t *__restrict
     const uint32_t n = load_count(n_dev, n_bound);
     const int nblk = (int)(((unsigned long long)n + TILE - 1) / TILE);
     uint32_t *row = hist + (size_t)blockIdx.x * hist_blocks;
-    // 64-bit running sums, stored saturated: the fused binning's column totals may in principle pass 2^32 (then every
-    // position derived from them lies beyond max_pairs and the frame is reported as overflowed, never written out of bounds)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long carry = 0;
+    uint32_t carry = 0;
     for (int base = 0; base < nblk; base += 1024) {
         const int i0 = base + threadIdx.x * 4;
         uint32_t v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = (i0 + j < nblk) ? row[i0 + j] : 0u;
-        const unsigned long long mine = (unsigned long long)v[0] + v[1] + v[2] + v[3];
-        unsigned long long incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        unsigned long long wbase = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const unsigned long long sw = wsum[w];
-            if (w < wave) wbase += sw;
-            total += sw;
-        }
-        __syncthreads();
-        unsigned long long ex = carry + wbase + (incl - mine);
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        uint32_t total;
+        uint32_t ex = block_excl_scan_256(mine, scratch, &total) + carry;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (i0 + j < nblk) row[i0 + j] = ex > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ex;
+            if (i0 + j < nblk) row[i0 + j] = ex;
             ex += v[j];
         }
         carry += total;
     }
-    if (threadIdx.x == 0) ctrl->digit_tot[blockIdx.x] = carry > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)carry;
+    if (threadIdx.x == 0) ctrl->digit_tot[blockIdx.x] = carry;
 }
 
-template <int DIGITS, bool DROP, int ITEMS, bool HAS_V2, bool INDEX_VALS>
-__global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
+template <int THREADS, bool DROP, int ITEMS, bool HAS_V2, bool INDEX_VALS>
+__global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint32_t *__restrict__ vals2_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t *__restrict__ vals2_out, const uint32_t *n_dev,
     uint32_t n_bound, PassSpec ps, const FrameCtrl *ctrl, const uint32_t *__restrict__ hist, int hist_blocks, uint32_t *n_out)
 {
-    using Smem = RadixTileSmem<DIGITS, ITEMS, HAS_V2>;
+    using Smem = RadixTileSmem<THREADS, ITEMS, HAS_V2>;
     constexpr int TILE = Smem::TILE;
-    constexpr int DPT = DIGITS / SORT_THREADS;
     __shared__ Smem sm;
-    __shared__ uint32_t digit_base[DIGITS];  // global position of this tile's run of digit d
+    __shared__ uint32_t digit_base[THREADS];  // global position of this tile's run of digit d
 
     int shift;
     uint32_t mask;
@@ -209,20 +185,12 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     radix_rank(sm, dig, rank);
     __syncthreads();
 
-    uint32_t cnt[DPT];
-    radix_tile_layout(sm, cnt);
+    radix_tile_layout(sm);
     {  // global digit bases: exclusive scan of the digit totals + this tile's entry of the scanned histogram
-        const int d0 = DPT * tid;
-        uint32_t tot[DPT], mine = 0;
-#pragma unroll
-        for (int j = 0; j < DPT; ++j) { tot[j] = ctrl->digit_tot[d0 + j]; mine += tot[j]; }
+        const uint32_t tot = ctrl->digit_tot[tid];
         uint32_t all_total;
-        uint32_t gs = block_excl_scan_256(mine, sm.scratch, &all_total);
-#pragma unroll
-        for (int j = 0; j < DPT; ++j) {
-            digit_base[d0 + j] = gs + hist[(size_t)(d0 + j) * hist_blocks + blockIdx.x];
-            gs += tot[j];
-        }
+        const uint32_t gs = block_excl_scan<THREADS>(tot, sm.scratch, &all_total);
+        digit_base[tid] = gs + hist[(size_t)tid * hist_blocks + blockIdx.x];
         if (n_out != nullptr && blockIdx.x == 0 && tid == 0) *n_out = all_total;
     }
     __syncthreads();
@@ -231,7 +199,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     __syncthreads();
 
     const uint32_t nvalid = sm.n_valid;
-    for (uint32_t i = tid; i < nvalid; i += SORT_THREADS) {
+    for (uint32_t i = tid; i < nvalid; i += THREADS) {
         const uint32_t k = sm.skey[i];
         const uint32_t d = ((k - ps.key_base) >> shift) & mask;
         const uint32_t gpos = digit_base[d] + (i - sm.tile_start[d]);
@@ -242,33 +210,23 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
 }
 
 // One pass = hist + rowscan + scatter.  `first` = pass 0 of a sort (may drop, may synthesise the index payload).
-template <int DIGITS, int ITEMS, bool HAS_V2>
+template <int THREADS, int ITEMS, bool HAS_V2>
 static void launch_pass(const uint32_t *kin, const uint32_t *vin, const uint32_t *v2in, uint32_t *kout, uint32_t *vout, uint32_t *v2out,
                         const uint32_t *cnt_dev, int64_t n_bound, const PassSpec &ps, bool drop, bool ident, uint32_t *n_out,
                         const Workspace &ws, hipStream_t s)
 {
-    constexpr int TILE = SORT_THREADS * ITEMS;
+    constexpr int TILE = THREADS * ITEMS;
     const int nblk = (int)((n_bound + TILE - 1) / TILE);
     const uint32_t nb = (uint32_t)n_bound;
 #define GSR_SCATTER(DROP, IDENT)                                                                                                   \
-    hipLaunchKernelGGL((radix_scatter_kernel<DIGITS, DROP, ITEMS, HAS_V2, IDENT>), dim3(nblk), dim3(SORT_THREADS), 0, s, kin, vin, v2in, \
+    hipLaunchKernelGGL((radix_scatter_kernel<THREADS, DROP, ITEMS, HAS_V2, IDENT>), dim3(nblk), dim3(THREADS), 0, s, kin, vin, v2in,   \
                        kout, vout, v2out, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks, n_out)
-    if (drop) hipLaunchKernelGGL((radix_hist_kernel<DIGITS, true, ITEMS>), dim3(nblk), dim3(SORT_THREADS), 0, s, kin, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks);
-    else hipLaunchKernelGGL((radix_hist_kernel<DIGITS, false, ITEMS>), dim3(nblk), dim3(SORT_THREADS), 0, s, kin, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks);
-    hipLaunchKernelGGL(radix_rowscan_kernel<TILE>, dim3(DIGITS), dim3(256), 0, s, ws.hist, ws.hist_blocks, cnt_dev, nb, ps, ws.ctrl);
+    if (drop) hipLaunchKernelGGL((radix_hist_kernel<THREADS, true, ITEMS>), dim3(nblk), dim3(THREADS), 0, s, kin, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks);
+    else hipLaunchKernelGGL((radix_hist_kernel<THREADS, false, ITEMS>), dim3(nblk), dim3(THREADS), 0, s, kin, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks);
+    hipLaunchKernelGGL(radix_rowscan_kernel<TILE>, dim3(THREADS), dim3(256), 0, s, ws.hist, ws.hist_blocks, cnt_dev, nb, ps, ws.ctrl);
     if (drop) { if (ident) GSR_SCATTER(true, true); else GSR_SCATTER(true, false); }
     else      { if (ident) GSR_SCATTER(false, true); else GSR_SCATTER(false, false); }
 #undef GSR_SCATTER
-}
-
-void launch_rowscan_blocks(const Workspace &ws, int rows, int block, const uint32_t *n_dev, int64_t n_bound, hipStream_t s)
-{
-    const PassSpec ps = {0, 0u, 0u, 0u, -1};
-    if (block == PAIR_BLOCK)
-        hipLaunchKernelGGL(radix_rowscan_kernel<PAIR_BLOCK>, dim3(rows), dim3(256), 0, s, ws.hist, ws.hist_blocks, n_dev, (uint32_t)n_bound, ps, ws.ctrl);
-    else
-        hipLaunchKernelGGL(radix_rowscan_kernel<SORT_THREADS * PAIR_SORT_ITEMS>, dim3(rows), dim3(256), 0, s, ws.hist, ws.hist_blocks, n_dev,
-                           (uint32_t)n_bound, ps, ws.ctrl);
 }
 
 // Depth order of the gaussians (rasterize.py:424-425).  Always four passes enqueued, 3 run on ordinary scenes (header).
@@ -276,7 +234,7 @@ void launch_rowscan_blocks(const Workspace &ws, int rows, int block, const uint3
 int launch_depth_sort(const Workspace &ws, bool packed_rect, hipStream_t s)
 {
     if (ws.n <= 0) return GSR_OK;
-    constexpr int TILE = SORT_THREADS * DEPTH_SORT_ITEMS;
+    constexpr int TILE = DEPTH_SORT_THREADS * DEPTH_SORT_ITEMS;
     const int nblk = (int)((ws.n + TILE - 1) / TILE);
     if (nblk > ws.hist_blocks) { set_error("radix sort: %d tiles exceed the histogram stride %d", nblk, ws.hist_blocks); return GSR_ERR_WORKSPACE; }
     const uint32_t *cnt_dev = nullptr;
@@ -285,10 +243,10 @@ int launch_depth_sort(const Workspace &ws, bool packed_rect, hipStream_t s)
         const int in = p & 1, out = in ^ 1;
         const bool first = p == 0;
         if (packed_rect)
-            launch_pass<512, DEPTH_SORT_ITEMS, true>(ws.key[in], ws.val[in], ws.rect8[in], ws.key[out], ws.val[out], ws.rect8[out], cnt_dev, ws.n, ps,
+            launch_pass<DEPTH_SORT_THREADS, DEPTH_SORT_ITEMS, true>(ws.key[in], ws.val[in], ws.rect8[in], ws.key[out], ws.val[out], ws.rect8[out], cnt_dev, ws.n, ps,
                                                      first, first, first ? &ws.ctrl->n_visible : nullptr, ws, s);
         else
-            launch_pass<512, DEPTH_SORT_ITEMS, false>(ws.key[in], ws.val[in], nullptr, ws.key[out], ws.val[out], nullptr, cnt_dev, ws.n, ps,
+            launch_pass<DEPTH_SORT_THREADS, DEPTH_SORT_ITEMS, false>(ws.key[in], ws.val[in], nullptr, ws.key[out], ws.val[out], nullptr, cnt_dev, ws.n, ps,
                                                       first, first, first ? &ws.ctrl->n_visible : nullptr, ws, s);
         cnt_dev = &ws.ctrl->n_visible;  // later passes only see the survivors
     }
@@ -306,7 +264,7 @@ int launch_pair_sort(const Workspace &ws, int in_buf, const uint32_t *n_dev, int
 {
     *result_buf = in_buf;
     if (ws.max_pairs <= 0 || key_bits <= first_bit) return GSR_OK;
-    constexpr int TILE = SORT_THREADS * PAIR_SORT_ITEMS;
+    constexpr int TILE = PAIR_SORT_THREADS * PAIR_SORT_ITEMS;
     const int nblk = (int)((ws.max_pairs + TILE - 1) / TILE);
     if (nblk > ws.hist_blocks) { set_error("radix sort: %d tiles exceed the histogram stride %d", nblk, ws.hist_blocks); return GSR_ERR_WORKSPACE; }
     const int bits = key_bits - first_bit;
@@ -318,7 +276,7 @@ int launch_pair_sort(const Workspace &ws, int in_buf, const uint32_t *n_dev, int
         const int shift = first_bit + bits_pp * p;
         const PassSpec ps = {shift, (1u << std::min(bits_pp, key_bits - shift)) - 1u, 0u, drop_from, -1};
         const bool first = p == 0;
-        launch_pass<256, PAIR_SORT_ITEMS, false>(ws.pkey[cur], ws.pval[cur], nullptr, ws.pkey[cur ^ 1], ws.pval[cur ^ 1], nullptr, cnt_dev,
+        launch_pass<PAIR_SORT_THREADS, PAIR_SORT_ITEMS, false>(ws.pkey[cur], ws.pval[cur], nullptr, ws.pkey[cur ^ 1], ws.pval[cur ^ 1], nullptr, cnt_dev,
                                                  ws.max_pairs, ps, first, false, first ? n_out : nullptr, ws, s);
         if (first && n_out) cnt_dev = n_out;
         cur ^= 1;
