@@ -3,6 +3,7 @@
 // Prints cycles per wave64 instruction per SIMD (from wall time and s_memtime clock).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define REP16(x) x x x x x x x x x x x x x x x x
@@ -45,6 +46,40 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, unsigned long lo
             REP16(asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
                                "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
                                : "+v"(a0) : "v"(b), "v"(c));)
+        } else if (KIND == 8 || KIND == 9) {  // v_fma_f32 with EXEC = lanes 0..31 only (8) / even lanes only (9): does an empty 32-lane half skip its pass?
+            const int l = threadIdx.x & 63;
+            if (KIND == 8 ? (l < 32) : ((l & 1) == 0)) {
+                REP16(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                                   "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
+            }
+        } else if (KIND == 10) {  // v_exp_f32 with EXEC = lanes 0..31 only
+            if ((threadIdx.x & 63) < 32) {
+                REP16(asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n"
+                                   "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n"
+                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+            }
+        } else if (KIND == 11) {  // v_cmp alone (result to an SGPR pair, never read by a VALU)
+            unsigned long long m0, m1, m2, m3;
+            REP16(asm volatile("v_cmp_gt_f32 %0, %4, %8\n v_cmp_gt_f32 %1, %5, %8\n v_cmp_gt_f32 %2, %6, %8\n v_cmp_gt_f32 %3, %7, %8\n"
+                               "v_cmp_gt_f32 %0, %5, %8\n v_cmp_gt_f32 %1, %6, %8\n v_cmp_gt_f32 %2, %7, %8\n v_cmp_gt_f32 %3, %4, %8\n"
+                               : "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b));)
+            a4 += (float)(unsigned)(m0 ^ m1 ^ m2 ^ m3);
+        } else if (KIND == 12) {  // v_cndmask alone (mask in a fixed SGPR pair)
+            const unsigned long long msk = 0x5555AAAA5555AAAAull ^ (unsigned long long)i;
+            REP16(asm volatile("v_cndmask_b32 %0, %1, %0, %4\n v_cndmask_b32 %1, %2, %1, %4\n v_cndmask_b32 %2, %3, %2, %4\n v_cndmask_b32 %3, %0, %3, %4\n"
+                               "v_cndmask_b32 %0, %1, %0, %4\n v_cndmask_b32 %1, %2, %1, %4\n v_cndmask_b32 %2, %3, %2, %4\n v_cndmask_b32 %3, %0, %3, %4\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "s"(msk));)
+        } else if (KIND == 13) {  // v_cmpx + 3 v_fma under the new EXEC + restore (the masked-update form of the blend)
+            REP16(asm volatile("v_cmpx_gt_f32 %0, %4\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n s_mov_b64 exec, -1\n"
+                               "v_cmpx_gt_f32 %1, %4\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n s_mov_b64 exec, -1\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");)
+        } else if (KIND == 14) {  // v_readlane_b32 (VGPR lane -> SGPR)
+            unsigned s0, s1, s2, s3;
+            REP16(asm volatile("v_readlane_b32 %0, %4, 3\n v_readlane_b32 %1, %5, 17\n v_readlane_b32 %2, %6, 40\n v_readlane_b32 %3, %7, 63\n"
+                               "v_readlane_b32 %0, %5, 5\n v_readlane_b32 %1, %6, 19\n v_readlane_b32 %2, %7, 42\n v_readlane_b32 %3, %4, 61\n"
+                               : "=s"(s0), "=s"(s1), "=s"(s2), "=s"(s3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));)
+            a4 += (float)(s0 ^ s1 ^ s2 ^ s3);
         } else if (KIND == 7) {  // ds_read_b128 broadcast (all lanes same address)
             __shared__ float4 buf[256];
             if (i == 0) buf[threadIdx.x] = make_float4(a0, a1, a2, a3);
@@ -89,6 +124,13 @@ void run(const char *name, int blocks_per_cu, int instr_per_iter)
 
 int main()
 {
+    for (int w : {2, 8}) {
+        run<0>("v_fma_f32 x8 indep", w, 128); run<8>("v_fma_f32 EXEC=lanes 0-31", w, 128); run<9>("v_fma_f32 EXEC=even lanes", w, 128);
+        run<2>("v_exp_f32", w, 128); run<10>("v_exp_f32 EXEC=lanes 0-31", w, 128);
+        run<3>("v_cmp+v_cndmask pairs", w, 128); run<11>("v_cmp alone (to SGPR)", w, 128); run<12>("v_cndmask alone", w, 128);
+        run<13>("v_cmpx + 3 fma + s_mov exec", w, 128 + 32); run<14>("v_readlane_b32", w, 128);
+    }
+    if (getenv("GSR_MICROBENCH_FULL"))
     for (int w : {1, 2, 4, 8}) {
         if (w == 1) { run<0>("v_fma_f32 x8 indep", 1, 128); run<1>("v_mul_f32", 1, 128); run<2>("v_exp_f32", 1, 128); run<3>("v_cmp+v_cndmask", 1, 128); run<4>("v_pk_fma_f32", 1, 128); run<5>("v_sub_f32", 1, 128); run<6>("v_fma_f32 dependent", 1, 128); run<7>("ds_read_b128 bcast+wait", 1, 16); }
         if (w == 2) { run<0>("v_fma_f32 x8 indep", 2, 128); run<1>("v_mul_f32", 2, 128); run<2>("v_exp_f32", 2, 128); run<3>("v_cmp+v_cndmask", 2, 128); run<4>("v_pk_fma_f32", 2, 128); run<6>("v_fma_f32 dependent", 2, 128); run<7>("ds_read_b128 bcast+wait", 2, 16); }

@@ -55,6 +55,80 @@ __device__ __forceinline__ void blend_one(const float2 g, const float4 c, const 
     T = T - w;
 }
 
+// The same evaluation with the update EXEC-masked instead of selected: v_cmpx writes the validity test straight into EXEC
+// (1.1 ns per wave-instruction measured, tools/valu_microbench.hip; v_cmp to an SGPR pair costs 1.76 ns and the
+// v_cndmask that consumes it 1.83 ns), the five update instructions run under it and EXEC is restored by one scalar move.
+// Lanes that fail the test keep C and T untouched, exactly what adding w = 0 did: results are bit-identical to blend_one.
+// One asm statement, so the compiler never sees a modified EXEC; every lane of the wave is active at the call sites.
+__device__ __forceinline__ void blend_one_x(const float2 g, const float4 c, const float4 o, float fpx, float fpy, float &T,
+                                            float &Cr, float &Cg, float &Cb)
+{
+    float dx, dy, t0, t1;
+    asm volatile(
+        "v_sub_f32 %4, %8, %16\n\t"          // dx = g.x - fpx
+        "v_sub_f32 %5, %9, %17\n\t"          // dy = g.y - fpy
+        "v_mul_f32 %6, %10, %4\n\t"          // c.x * dx
+        "v_fma_f32 %6, %11, %5, %6\n\t"      // t0 = fma(c.y, dy, c.x * dx)
+        "v_mul_f32 %7, %12, %5\n\t"          // c.z * dy
+        "v_fma_f32 %7, %7, %5, %13\n\t"      // t1 = fma(c.z * dy, dy, L)
+        "v_fma_f32 %6, %4, %6, %7\n\t"       // p = fma(dx, t0, t1)
+        "v_exp_f32 %7, %6\n\t"               // 2^p
+        "v_cmpx_le_f32 vcc, %6, %13\n\t"     // EXEC &= p <= L   (power <= 0, rasterize.py:291).  Sits here on purpose: a VALU that
+                                               // consumes a transcendental's result needs one wait state on gfx940+ (the compiler
+                                               // inserts it for its own code, never inside inline asm) — this instruction is it
+        "v_min_f32 %7, 0x3f7d70a4, %7\n\t"   // alpha = min(., 0.99)
+        "v_cmpx_lt_f32 vcc, 0x3b808081, %7\n\t"  // EXEC &= 1/255 < alpha
+        "v_mul_f32 %4, %0, %7\n\t"           // w = T * alpha
+        "v_fma_f32 %1, %4, %14, %1\n\t"
+        "v_fma_f32 %2, %4, %15, %2\n\t"
+        "v_fma_f32 %3, %4, %18, %3\n\t"
+        "v_fma_f32 %0, -%0, %7, %0\n\t"      // T = T - T * alpha, one rounding: what the compiler makes of blend_one's T - w
+        "s_mov_b64 exec, -1"
+        : "+v"(T), "+v"(Cr), "+v"(Cg), "+v"(Cb), "=&v"(dx), "=&v"(dy), "=&v"(t0), "=&v"(t1)
+        : "v"(g.x), "v"(g.y), "v"(c.x), "v"(c.y), "v"(c.z), "v"(o.x), "v"(o.y), "v"(o.z), "v"(fpx), "v"(fpy), "v"(o.w),
+          "v"(c.w)  // unused: keeps the record's second read a ds_read_b128 (4 LDS cycles; a b96 costs 8)
+        : "vcc");
+}
+
+// blend_one_x with one more wave-uniform condition ANDed into EXEC (the update runs only if the wave-uniform `gate` is non-zero): lets the survivor walk run two
+// evaluations per trip as straight-line code, the second one switched off when the survivor count is odd.
+__device__ __forceinline__ void blend_one_xg(const float2 g, const float4 c, const float4 o, float fpx, float fpy, float &T,
+                                             float &Cr, float &Cg, float &Cb, unsigned long long gate)
+{
+    float dx, dy, t0, t1;
+    asm volatile(
+        "v_sub_f32 %4, %8, %16\n\t"
+        "v_sub_f32 %5, %9, %17\n\t"
+        "v_mul_f32 %6, %10, %4\n\t"
+        "v_fma_f32 %6, %11, %5, %6\n\t"
+        "v_mul_f32 %7, %12, %5\n\t"
+        "v_fma_f32 %7, %7, %5, %13\n\t"
+        "v_fma_f32 %6, %4, %6, %7\n\t"
+        "v_exp_f32 %7, %6\n\t"
+        "v_cmpx_le_f32 vcc, %6, %13\n\t"
+        "v_min_f32 %7, 0x3f7d70a4, %7\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, %7\n\t"
+        "s_cmp_lg_u64 %20, 0\n\t"
+        "s_cselect_b64 exec, exec, 0\n\t"
+        "v_mul_f32 %4, %0, %7\n\t"
+        "v_fma_f32 %1, %4, %14, %1\n\t"
+        "v_fma_f32 %2, %4, %15, %2\n\t"
+        "v_fma_f32 %3, %4, %18, %3\n\t"
+        "v_fma_f32 %0, -%0, %7, %0\n\t"
+        "s_mov_b64 exec, -1"
+        : "+v"(T), "+v"(Cr), "+v"(Cg), "+v"(Cb), "=&v"(dx), "=&v"(dy), "=&v"(t0), "=&v"(t1)
+        : "v"(g.x), "v"(g.y), "v"(c.x), "v"(c.y), "v"(c.z), "v"(o.x), "v"(o.y), "v"(o.z), "v"(fpx), "v"(fpy), "v"(o.w), "v"(c.w), "s"(gate)
+        : "vcc", "scc");
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void blend_eval(const float2 g, const float4 c, const float4 o, float fpx, float fpy, float &T,
+                                           float &Cr, float &Cg, float &Cb)
+{
+    if (MASKED) blend_one_x(g, c, o, fpx, fpy, T, Cr, Cg, Cb);
+    else blend_one(g, c, o, fpx, fpy, T, Cr, Cg, Cb);
+}
+
 // Tile launch order.  Group g = tile rows g, g+8, ... of the shard (one XCD's share).  One workgroup per
 // group bucket-sorts its tiles by list length, longest first (buckets = exponent + 3 mantissa bits of the
 // length, i.e. within 12.5 %): order[8*j + g] = j-th tile of group g.  Slots past the end of a group hold -1.
@@ -102,6 +176,7 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict
     }
 }
 
+template <bool MASKED, int DBG = 0>
 __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
 {
     __shared__ float4 s0[256];
@@ -149,24 +224,54 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
             const bool hit = e < nb && footprint_hits_rect(s0[e], s1[e], qx0, qx1, qy0, qy1);
             unsigned long long m = __ballot(hit);
             evaluated += (uint32_t)__popcll(m);
-            while (m) {
-                const int k0 = chunk + (__ffsll((long long)m) - 1);
-                m &= m - 1;
-                const float2 ga = *reinterpret_cast<const float2 *>(&s0[k0]);  // wave-uniform address: LDS broadcast
-                const float4 ca = s1[k0];
-                const float4 oa = s2[k0];
-                asm volatile("" ::"v"(ca.w));  // keep the read a ds_read_b128 (4 LDS cycles); a b96 costs 8
-                if (m) {  // second survivor: its LDS reads are issued before the first one's arithmetic
-                    const int k1 = chunk + (__ffsll((long long)m) - 1);
+            // Survivor walk: two per trip, so that the second one's LDS broadcast reads overlap the first one's arithmetic.
+            if (MASKED) {
+                // straight-line body: with an odd count the last trip re-reads its survivor and evaluates it with EXEC gated
+                // off (~1 % of the evaluations) — any branch around the second evaluation makes the compiler shuffle T and
+                // the colour sums between registers on every trip (two extra VALU per entry)
+                while (m) {
+                    const int b0 = __ffsll((long long)m) - 1;
                     m &= m - 1;
+                    const unsigned long long m1 = m;  // survivors left after the first: zero gates the second evaluation off
+                    const int b1 = m1 ? __ffsll((long long)m1) - 1 : b0;
+                    m &= m - 1;
+                    const int k0 = chunk + b0, k1 = chunk + b1;
+                    const float2 ga = *reinterpret_cast<const float2 *>(&s0[k0]);  // wave-uniform address: LDS broadcast
+                    const float4 ca = s1[k0];
+                    const float4 oa = s2[k0];
                     const float2 gb = *reinterpret_cast<const float2 *>(&s0[k1]);
                     const float4 cb = s1[k1];
                     const float4 ob = s2[k1];
-                    asm volatile("" ::"v"(cb.w));
-                    blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
-                    blend_one(gb, cb, ob, fpx, fpy, T, Cr, Cg, Cb);
-                } else {
-                    blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
+                    if (DBG == 4) {
+                        asm volatile("" ::"v"(ca.w), "v"(cb.w));
+                        blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
+                        if (m1) blend_one(gb, cb, ob, fpx, fpy, T, Cr, Cg, Cb);
+                    } else {
+                    blend_one_x(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
+                    blend_one_xg(gb, cb, ob, fpx, fpy, T, Cr, Cg, Cb, m1);
+                    }
+                }
+            } else {
+                while (m) {
+                    const int k0 = chunk + (__ffsll((long long)m) - 1);
+                    m &= m - 1;
+                    const float2 ga = *reinterpret_cast<const float2 *>(&s0[k0]);
+                    const float4 ca = s1[k0];
+                    const float4 oa = s2[k0];
+                    asm volatile("" ::"v"(ca.w));
+                    if (m) {
+                        const int k1 = chunk + (__ffsll((long long)m) - 1);
+                        m &= m - 1;
+                        const float2 gb = *reinterpret_cast<const float2 *>(&s0[k1]);
+                        const float4 cb = s1[k1];
+                        const float4 ob = s2[k1];
+                        asm volatile("" ::"v"(cb.w));
+                        if (DBG == 5) { blend_one_x(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb); blend_one_x(gb, cb, ob, fpx, fpy, T, Cr, Cg, Cb); }
+                        else { blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb); blend_one(gb, cb, ob, fpx, fpy, T, Cr, Cg, Cb); }
+                    } else {
+                        if (DBG == 5) blend_one_x(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
+                        else blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
+                    }
                 }
             }
             if (__all(T <= a.early_T)) {
@@ -192,6 +297,119 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
                             : a.layout == 0 ? (size_t)py * a.W + px
                                             : (size_t)(((ty - a.row_begin) / a.row_step) * 16 + (py - ty * 16)) * a.W + px;
             a.out_T[ot] = drawn ? T : 1.0f;
+        }
+    }
+}
+
+// Half-tile variant (GsrOptions.blend_impl = 3): one 128-thread workgroup per 16x16 tile, wave w = the 16x8 half (pixel rows
+// 8w .. 8w+7), a lane = TWO pixels 8 columns apart, one in each 8x8 quadrant of the half.  Same lists, same per-quadrant
+// culling and saturation tests, same per-pixel arithmetic in the same order as blend_kernel — frames are bit-identical — but
+// an entry that touches both quadrants of a half is read from LDS once instead of twice and walked by the scalar loop once:
+// the LDS pipe (three broadcast reads = 10 LDS cycles per evaluated (wave, entry)) is what blend_kernel saturates together
+// with VALU issue.
+__global__ __launch_bounds__(128) void blend_half_kernel(BlendArgs a)
+{
+    constexpr int BATCH = 128;
+    __shared__ float4 s0[BATCH];
+    __shared__ float4 s1[BATCH];
+    __shared__ float4 s2[BATCH];
+    __shared__ int s_done;
+
+    const int tile = a.order[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *stat = a.stats + (size_t)blockIdx.x * BLEND_STAT_WORDS;
+    if (tile < 0) {  // uniform: empty launch slot
+        if (tid < 5) stat[tid] = 0;
+        return;
+    }
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int qx = tx * 16, qy = ty * 16 + wave * 8;
+    const int px = qx + (lane & 7), py = qy + (lane >> 3);  // pixel A; pixel B = (px + 8, py)
+    const float fpxA = (float)px, fpxB = (float)(px + 8), fpy = (float)py;
+    const float xa0 = (float)qx, xa1 = (float)(qx + 7), xb0 = (float)(qx + 8), xb1 = (float)(qx + 15);
+    const float qy0 = (float)qy, qy1 = (float)(qy + 7);
+
+    const uint2 range = a.ranges[tile];
+    float TA = 1.0f, CrA = 0.0f, CgA = 0.0f, CbA = 0.0f;
+    float TB = 1.0f, CrB = 0.0f, CgB = 0.0f, CbB = 0.0f;
+    bool doneA = false, doneB = false;  // wave-uniform: quadrant saturated
+    uint32_t evaluated = 0;             // wave-uniform
+    uint32_t fetched = 0;               // workgroup-uniform
+    if (tid == 0) s_done = 0;
+
+    for (uint32_t batch = range.x; batch < range.y; batch += BATCH) {
+        __syncthreads();  // previous batch fully consumed (and s_done initialised)
+        if (s_done == 2) break;  // uniform: both waves saturated
+        const uint32_t i = batch + tid;
+        fetched += min((uint32_t)BATCH, range.y - batch);
+        if (i < range.y) {
+            const GaussRec *r = a.rec + a.pval[i];
+            s0[tid] = r->q0;
+            s1[tid] = r->q1;
+            s2[tid] = r->q2;
+        }
+        __syncthreads();
+        if (doneA && doneB) continue;
+        const int nb = min((uint32_t)BATCH, range.y - batch);
+        for (int chunk = 0; chunk < nb; chunk += 64) {
+            const int e = chunk + lane;
+            bool hitA = false, hitB = false;
+            if (e < nb) {
+                const float4 q0 = s0[e], q1 = s1[e];
+                hitA = !doneA && footprint_hits_rect(q0, q1, xa0, xa1, qy0, qy1);
+                hitB = !doneB && footprint_hits_rect(q0, q1, xb0, xb1, qy0, qy1);
+            }
+            const unsigned long long mA = __ballot(hitA), mB = __ballot(hitB);
+            evaluated += (uint32_t)__popcll(mA) + (uint32_t)__popcll(mB);
+            unsigned long long m = mA | mB;
+            while (m) {
+                const int b0 = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int k0 = chunk + b0;
+                const float2 ga = *reinterpret_cast<const float2 *>(&s0[k0]);  // wave-uniform address: LDS broadcast
+                const float4 ca = s1[k0];
+                const float4 oa = s2[k0];
+                asm volatile("" ::"v"(ca.w));  // keep the read a ds_read_b128 (4 LDS cycles); a b96 costs 8
+                if (m) {  // second survivor: its LDS reads are issued before the first one's arithmetic
+                    const int b1 = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int k1 = chunk + b1;
+                    const float2 gb = *reinterpret_cast<const float2 *>(&s0[k1]);
+                    const float4 cb = s1[k1];
+                    const float4 ob = s2[k1];
+                    asm volatile("" ::"v"(cb.w));
+                    if ((mA >> b0) & 1ull) blend_one(ga, ca, oa, fpxA, fpy, TA, CrA, CgA, CbA);
+                    if ((mB >> b0) & 1ull) blend_one(ga, ca, oa, fpxB, fpy, TB, CrB, CgB, CbB);
+                    if ((mA >> b1) & 1ull) blend_one(gb, cb, ob, fpxA, fpy, TA, CrA, CgA, CbA);
+                    if ((mB >> b1) & 1ull) blend_one(gb, cb, ob, fpxB, fpy, TB, CrB, CgB, CbB);
+                } else {
+                    if ((mA >> b0) & 1ull) blend_one(ga, ca, oa, fpxA, fpy, TA, CrA, CgA, CbA);
+                    if ((mB >> b0) & 1ull) blend_one(ga, ca, oa, fpxB, fpy, TB, CrB, CgB, CbB);
+                }
+            }
+            if (!doneA && __all(TA <= a.early_T)) doneA = true;
+            if (!doneB && __all(TB <= a.early_T)) doneB = true;
+            if (doneA && doneB) {
+                if (lane == 0) atomicAdd(&s_done, 1);
+                break;
+            }
+        }
+    }
+
+    if (lane == 0) { stat[wave] = evaluated; stat[2 + wave] = 0; }
+    if (tid == 0) stat[4] = fetched;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int x = px + 8 * h;
+        const float T = h ? TB : TA, Cr = h ? CrB : CrA, Cg = h ? CgB : CgA, Cb = h ? CbB : CbA;
+        if (x < a.W && py < a.H) {
+            const bool drawn = x < a.xlim && py < a.ylim;  // Q1: last column / row stay black, T stays 1
+            const float r = drawn ? Cr : 0.0f, g = drawn ? Cg : 0.0f, b = drawn ? Cb : 0.0f;
+            const size_t pix = a.layout == 0 ? (size_t)py * a.W + x                                           // image [H,W,3]
+                             : a.layout == 1 ? (size_t)x * a.H + py                                           // screen [W,H,3]
+                                             : (size_t)(((ty - a.row_begin) / a.row_step) * 16 + (py - ty * 16)) * a.W + x;  // strip
+            store_rgb(a, pix * 3, r, g, b);
+            if (a.out_T) a.out_T[pix] = drawn ? T : 1.0f;
         }
     }
 }
@@ -224,7 +442,11 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
                        slots_per_group, ws.tile_order,
                        (uint32_t)(reinterpret_cast<const char *>(ws.blend_stats) - reinterpret_cast<const char *>(ws.ctrl)));
     if (opts.blend_impl == 2) return launch_blend_mfma(a, 8u * (unsigned)slots_per_group, s);
-    hipLaunchKernelGGL(blend_kernel, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
+    if (opts.blend_impl == 3) hipLaunchKernelGGL(blend_half_kernel, dim3(8u * (unsigned)slots_per_group), dim3(128), 0, s, a);
+    else if (opts.blend_impl == 4) hipLaunchKernelGGL((blend_kernel<true, 4>), dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
+    else if (opts.blend_impl == 5) hipLaunchKernelGGL((blend_kernel<false, 5>), dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
+    else if (opts.blend_impl == 1) hipLaunchKernelGGL(blend_kernel<false>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(blend_kernel<true>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }
