@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--workload", default="bicycle", choices=sorted(WORKLOADS))
     ap.add_argument("--gaussians", type=int, default=0, help="override the gaussian count (0 = the workload's)")
     ap.add_argument("--early-out-T", type=float, default=0.0)
-    ap.add_argument("--blend-impl", type=int, default=0, help="0 default blend, 2 experimental matrix-pipe blend")
+    ap.add_argument("--blend-impl", type=int, default=0, help="0 default blend, 1 the same with its walk in plain C, 2 experimental matrix-pipe blend")
     ap.add_argument("--sh-half", action="store_true", help="headline with SH coefficients stored as fp16 (default: fp32, the reference's type)")
     ap.add_argument("--bf16-output", action="store_true", help="headline with the frame stored as bfloat16; accumulation stays fp32")
     ap.add_argument("--camera", type=int, default=0)
@@ -264,7 +264,7 @@ def main():
                        "sharding": f"tile rows interleaved over {world} GPU(s), RCCL gather to rank 0" if world > 1 else "none",
                        "reference_compat": True, "early_out_T": args.early_out_T, "sh_storage": "f16" if args.sh_half else "f32",
                        "frame_storage": "bf16 (fp32 accumulation)" if args.bf16_output else "f32",
-                       "blend_impl": "mfma (experimental)" if args.blend_impl == 2 else "valu"},
+                       "blend_impl": {0: "valu", 1: "valu, plain-C walk", 2: "mfma (experimental)"}[args.blend_impl]},
             "stats_rank0_shard": shard_stats,
         }
 

@@ -84,10 +84,12 @@ typedef struct GsrOptions {
     int32_t no_footprint_cull;/* 0 (default): tile rects / quadrant tests are tightened to the AABB of the region where
                                  alpha > 1/255 can hold (exact: skipped work contributes nothing).  1: bin the
                                  reference's full 3-sigma tile rect — only to prove that property in tests. */
-    int32_t blend_impl;       /* 0 (default) / 1: per-pixel quadratic on the vector ALU, the reference's arithmetic to the ulp.
-                                 2: quadratic evaluated on the matrix pipe (v_mfma_f32_32x32x2_f32) as [gaussian coefficients]
-                                 x [pixel basis]: same frame within ~1e-5 absolute in the exponent (measured 125 dB vs the oracle); an
-                                 experiment: 33 % fewer VALU instructions but currently ~6 % slower (see blend_mfma.hip). */
+    int32_t blend_impl;       /* 0 (default): the blend kernel with its inner walk hand-scheduled (EXEC-masked update, csrc/blend.hip).
+                                 1: the same kernel with the walk in plain C — the readable statement of the arithmetic and the A/B
+                                 reference; frames are bit-identical to 0.
+                                 2: EXPERIMENTAL, not the product path: quadratic evaluated on the matrix pipe
+                                 (v_mfma_f32_32x32x2_f32) as [gaussian coefficients] x [pixel basis]; same frame within ~1e-5 absolute
+                                 in the exponent (125 dB vs the oracle), not faster (see blend_mfma.hip). */
     int32_t draw_limit;       /* 0 (default): blend everything.  k > 0: blend only the first k gaussians of the reference's
                                  draw order (depth order restricted to those its skip guard rasterize.py:441 lets through) —
                                  the progressive frames of --generate_video (rasterize.py:448-450). */

@@ -533,3 +533,24 @@ def test_depth_sort_plans_its_passes_from_the_key_range(G):
     assert_frames_close(fimg, foimg)
     # the plan is per frame: the near scene on the far scene's workspace geometry goes back to 3 passes
     assert torch.equal(R.render(cam), torch.from_numpy(img).to("cuda")) and _ctrl_word(R, cam, SORT_PASSES_OFFSET) == 3
+
+
+def test_hand_scheduled_blend_walk_equals_the_plain_kernel(G):
+    """blend.hip: the default kernel walks its survivors in one hand-written asm statement (EXEC-masked update, rolling LDS
+    prefetch); blend_impl = 1 is the same kernel with that walk in plain C.  Same instructions on the data path, so frames,
+    transmittance and counters must be identical bit for bit — whole frames, shards, early-out, bf16 store, non-compat, the
+    fixtures with their edge cases (a frame-covering gaussian, the 0.99 cap, frames not a multiple of 16)."""
+    mk = G.renderer.make_options
+    cases = [_medium(G)[:2], _medium(G, n=300_000, shift=1.6, pose=7)[:2]]
+    for name, prefix in (("f2_small.npz", ""), ("f3_edge.npz", "a_"), ("f3_edge.npz", "b_")):
+        g = load_golden(name)
+        cases.append((golden_columns(g), _cams(G, g, prefix)[0]))
+    for cols, cam in cases:
+        R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
+        for kw in (dict(), dict(early_out_T=1e-4), dict(tile_row_begin=2, tile_row_step=5, output_layout=2), dict(output_bf16=True),
+                   dict(reference_compat=False), dict(output_layout=1), dict(no_footprint_cull=True)):
+            a, Ta = R.render(cam, mk(**kw), return_T=True)
+            sa = dict(R.last_stats)
+            b, Tb = R.render(cam, mk(blend_impl=1, **kw), return_T=True)
+            assert torch.equal(a, b) and torch.equal(Ta, Tb), kw
+            assert sa == R.last_stats, kw

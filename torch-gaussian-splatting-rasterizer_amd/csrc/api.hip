@@ -80,7 +80,7 @@ static int check_frame(int64_t n, const GsrCamera *cam, const GsrOptions *opts, 
     }
     if (opts->draw_limit < 0) { set_error("bad draw_limit %d", opts->draw_limit); return GSR_ERR_BAD_ARG; }
     if (opts->output_dtype != 0 && opts->output_dtype != 1) { set_error("bad output_dtype %d", opts->output_dtype); return GSR_ERR_BAD_ARG; }
-    if (opts->blend_impl < 0 || opts->blend_impl > 5) { set_error("bad blend_impl %d", opts->blend_impl); return GSR_ERR_BAD_ARG; }
+    if (opts->blend_impl < 0 || opts->blend_impl > 2) { set_error("bad blend_impl %d", opts->blend_impl); return GSR_ERR_BAD_ARG; }
     if (opts->output_layout < 0 || opts->output_layout > 2) { set_error("bad output_layout %d", opts->output_layout); return GSR_ERR_BAD_ARG; }
     if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) { set_error("workspace must be 256-byte aligned"); return GSR_ERR_BAD_ARG; }
     const size_t need = carve_workspace(workspace, n, cam->width, cam->height, max_pairs, ws);

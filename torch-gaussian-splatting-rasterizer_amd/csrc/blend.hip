@@ -55,78 +55,140 @@ __device__ __forceinline__ void blend_one(const float2 g, const float4 c, const 
     T = T - w;
 }
 
-// The same evaluation with the update EXEC-masked instead of selected: v_cmpx writes the validity test straight into EXEC
-// (1.1 ns per wave-instruction measured, tools/valu_microbench.hip; v_cmp to an SGPR pair costs 1.76 ns and the
-// v_cndmask that consumes it 1.83 ns), the five update instructions run under it and EXEC is restored by one scalar move.
-// Lanes that fail the test keep C and T untouched, exactly what adding w = 0 did: results are bit-identical to blend_one.
-// One asm statement, so the compiler never sees a modified EXEC; every lane of the wave is active at the call sites.
-__device__ __forceinline__ void blend_one_x(const float2 g, const float4 c, const float4 o, float fpx, float fpy, float &T,
-                                            float &Cr, float &Cg, float &Cb)
+// The survivor walk of one 64-entry chunk as ONE asm statement (m != 0 on entry): for every set bit of the ballot `m`, in
+// order, read the record from LDS (wave-uniform address: three broadcast reads) and blend it into the lane's pixel — the
+// arithmetic of blend_one above, instruction for instruction as the compiler emits it (w = T alpha, T = fma(-T, alpha, T)),
+// so frames are bit-identical to the plain kernel (blend_impl = 1; tools/blend_ab.py checks it).  What differs:
+//   - the validity test goes straight into EXEC: two v_cmpx, the five update instructions run under it, one s_mov restores
+//     EXEC.  tools/valu_microbench.hip: v_cmp to an SGPR pair 1.76 ns and the v_cndmask that consumes it 1.83 ns per
+//     wave-instruction per SIMD, v_cmpx 1.1 ns like any plain VALU.  Lanes that fail keep C and T untouched, which is what
+//     adding w = 0 did.
+//   - v_cmpx_le sits between v_exp_f32 and the v_min_f32 that consumes it: on gfx940+ a VALU reading a transcendental's result
+//     needs one wait state; the compiler inserts it for its own code, never inside inline asm (without it the first four lanes
+//     of every eight read a stale value — found by tools/cmpx_test.hip).
+//   - the walk itself costs 5 scalar instructions per survivor (s_ff1 + s_bitset0 pop, loop test, EXEC restore) instead of the
+//     compiler's 10.8 (64-bit m & (m - 1) as add/addc/and, address shifts, selects), and the accumulators never change
+//     registers (the compiler's one-or-two-per-trip loop copied T and the colour sums on every trip: 2 VALU per entry).
+//   - records roll through two register sets: while survivor k is evaluated the reads of survivor k+1 are in flight (counted
+//     waits: LDS returns in order; the lgkmcnt(0) up front retires anything older, scalar loads included, which do not).
+// Registers v40-v63 are named explicitly (an asm statement takes at most 30 operands): v40/v41 addresses then temporaries,
+// v42-v51 and v52-v61 the two records, v62/v63 temporaries; the kernel stays at 64 VGPRs = 8 waves per SIMD.
+// Measured on the bench frame (interleaved A/B in one process): 0.662 ms against 0.744 ms for the plain kernel; PMC: VALU
+// 21.4 -> 17.6, SALU 9.2 -> 5 instructions per evaluated (quadrant, entry).  Variants that did not pay: two quadrants per
+// wave (16x8 half-tiles, one LDS read for both: +4 %, the LDS pipe is not the limit); skipping the pass of an empty 32-lane
+// EXEC half (the hardware does not: 8x4 culling is pointless); the same walk without the rolling prefetch (equal: 8 waves per
+// SIMD already hide the LDS latency).  The text below is generated by tools/gen_blend_walk.py.
+// lds_chunk = LDS byte address of the chunk's first record (plane 0), identical in every lane.
+__device__ __forceinline__ void blend_walk_asm(unsigned long long m, unsigned lds_chunk, float fpx, float fpy, float &T, float &Cr,
+                                               float &Cg, float &Cb)
 {
-    float dx, dy, t0, t1;
+    int idx;
     asm volatile(
-        "v_sub_f32 %4, %8, %16\n\t"          // dx = g.x - fpx
-        "v_sub_f32 %5, %9, %17\n\t"          // dy = g.y - fpy
-        "v_mul_f32 %6, %10, %4\n\t"          // c.x * dx
-        "v_fma_f32 %6, %11, %5, %6\n\t"      // t0 = fma(c.y, dy, c.x * dx)
-        "v_mul_f32 %7, %12, %5\n\t"          // c.z * dy
-        "v_fma_f32 %7, %7, %5, %13\n\t"      // t1 = fma(c.z * dy, dy, L)
-        "v_fma_f32 %6, %4, %6, %7\n\t"       // p = fma(dx, t0, t1)
-        "v_exp_f32 %7, %6\n\t"               // 2^p
-        "v_cmpx_le_f32 vcc, %6, %13\n\t"     // EXEC &= p <= L   (power <= 0, rasterize.py:291).  Sits here on purpose: a VALU that
-                                               // consumes a transcendental's result needs one wait state on gfx940+ (the compiler
-                                               // inserts it for its own code, never inside inline asm) — this instruction is it
-        "v_min_f32 %7, 0x3f7d70a4, %7\n\t"   // alpha = min(., 0.99)
-        "v_cmpx_lt_f32 vcc, 0x3b808081, %7\n\t"  // EXEC &= 1/255 < alpha
-        "v_mul_f32 %4, %0, %7\n\t"           // w = T * alpha
-        "v_fma_f32 %1, %4, %14, %1\n\t"
-        "v_fma_f32 %2, %4, %15, %2\n\t"
-        "v_fma_f32 %3, %4, %18, %3\n\t"
-        "v_fma_f32 %0, -%0, %7, %0\n\t"      // T = T - T * alpha, one rounding: what the compiler makes of blend_one's T - w
-        "s_mov_b64 exec, -1"
-        : "+v"(T), "+v"(Cr), "+v"(Cg), "+v"(Cb), "=&v"(dx), "=&v"(dy), "=&v"(t0), "=&v"(t1)
-        : "v"(g.x), "v"(g.y), "v"(c.x), "v"(c.y), "v"(c.z), "v"(o.x), "v"(o.y), "v"(o.z), "v"(fpx), "v"(fpy), "v"(o.w),
-          "v"(c.w)  // unused: keeps the record's second read a ds_read_b128 (4 LDS cycles; a b96 costs 8)
-        : "vcc");
-}
-
-// blend_one_x with one more wave-uniform condition ANDed into EXEC (the update runs only if the wave-uniform `gate` is non-zero): lets the survivor walk run two
-// evaluations per trip as straight-line code, the second one switched off when the survivor count is odd.
-__device__ __forceinline__ void blend_one_xg(const float2 g, const float4 c, const float4 o, float fpx, float fpy, float &T,
-                                             float &Cr, float &Cg, float &Cb, unsigned long long gate)
-{
-    float dx, dy, t0, t1;
-    asm volatile(
-        "v_sub_f32 %4, %8, %16\n\t"
-        "v_sub_f32 %5, %9, %17\n\t"
-        "v_mul_f32 %6, %10, %4\n\t"
-        "v_fma_f32 %6, %11, %5, %6\n\t"
-        "v_mul_f32 %7, %12, %5\n\t"
-        "v_fma_f32 %7, %7, %5, %13\n\t"
-        "v_fma_f32 %6, %4, %6, %7\n\t"
-        "v_exp_f32 %7, %6\n\t"
-        "v_cmpx_le_f32 vcc, %6, %13\n\t"
-        "v_min_f32 %7, 0x3f7d70a4, %7\n\t"
-        "v_cmpx_lt_f32 vcc, 0x3b808081, %7\n\t"
-        "s_cmp_lg_u64 %20, 0\n\t"
-        "s_cselect_b64 exec, exec, 0\n\t"
-        "v_mul_f32 %4, %0, %7\n\t"
-        "v_fma_f32 %1, %4, %14, %1\n\t"
-        "v_fma_f32 %2, %4, %15, %2\n\t"
-        "v_fma_f32 %3, %4, %18, %3\n\t"
-        "v_fma_f32 %0, -%0, %7, %0\n\t"
-        "s_mov_b64 exec, -1"
-        : "+v"(T), "+v"(Cr), "+v"(Cg), "+v"(Cb), "=&v"(dx), "=&v"(dy), "=&v"(t0), "=&v"(t1)
-        : "v"(g.x), "v"(g.y), "v"(c.x), "v"(c.y), "v"(c.z), "v"(o.x), "v"(o.y), "v"(o.z), "v"(fpx), "v"(fpy), "v"(o.w), "v"(c.w), "s"(gate)
-        : "vcc", "scc");
-}
-
-template <bool MASKED>
-__device__ __forceinline__ void blend_eval(const float2 g, const float4 c, const float4 o, float fpx, float fpy, float &T,
-                                           float &Cr, float &Cg, float &Cb)
-{
-    if (MASKED) blend_one_x(g, c, o, fpx, fpy, T, Cr, Cg, Cb);
-    else blend_one(g, c, o, fpx, fpy, T, Cr, Cg, Cb);
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_ff1_i32_b64 %[idx], %[m]\n\t"
+        "s_bitset0_b64 %[m], %[idx]\n\t"
+        "v_lshl_add_u32 v40, %[idx], 4, %[base]\n\t"
+        "ds_read_b64 v[42:43], v40\n\t"
+        "ds_read_b128 v[44:47], v40 offset:4096\n\t"
+        "ds_read_b128 v[48:51], v40 offset:8192\n\t"
+        "1:\n\t"
+        "s_cmp_eq_u64 %[m], 0\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "s_ff1_i32_b64 %[idx], %[m]\n\t"
+        "s_bitset0_b64 %[m], %[idx]\n\t"
+        "v_lshl_add_u32 v41, %[idx], 4, %[base]\n\t"
+        "ds_read_b64 v[52:53], v41\n\t"
+        "ds_read_b128 v[54:57], v41 offset:4096\n\t"
+        "ds_read_b128 v[58:61], v41 offset:8192\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        "v_sub_f32 v40, v42, %[fpx]\n\t"
+        "v_sub_f32 v41, v43, %[fpy]\n\t"
+        "v_mul_f32 v62, v44, v40\n\t"
+        "v_fma_f32 v62, v45, v41, v62\n\t"
+        "v_mul_f32 v63, v46, v41\n\t"
+        "v_fma_f32 v63, v63, v41, v48\n\t"
+        "v_fma_f32 v62, v40, v62, v63\n\t"
+        "v_exp_f32 v63, v62\n\t"
+        "v_cmpx_le_f32 vcc, v62, v48\n\t"
+        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[T], v63\n\t"
+        "v_fma_f32 %[Cr], v40, v49, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v40, v50, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v40, v51, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_cmp_eq_u64 %[m], 0\n\t"
+        "s_cbranch_scc1 4f\n\t"
+        "s_ff1_i32_b64 %[idx], %[m]\n\t"
+        "s_bitset0_b64 %[m], %[idx]\n\t"
+        "v_lshl_add_u32 v40, %[idx], 4, %[base]\n\t"
+        "ds_read_b64 v[42:43], v40\n\t"
+        "ds_read_b128 v[44:47], v40 offset:4096\n\t"
+        "ds_read_b128 v[48:51], v40 offset:8192\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        "v_sub_f32 v40, v52, %[fpx]\n\t"
+        "v_sub_f32 v41, v53, %[fpy]\n\t"
+        "v_mul_f32 v62, v54, v40\n\t"
+        "v_fma_f32 v62, v55, v41, v62\n\t"
+        "v_mul_f32 v63, v56, v41\n\t"
+        "v_fma_f32 v63, v63, v41, v58\n\t"
+        "v_fma_f32 v62, v40, v62, v63\n\t"
+        "v_exp_f32 v63, v62\n\t"
+        "v_cmpx_le_f32 vcc, v62, v58\n\t"
+        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[T], v63\n\t"
+        "v_fma_f32 %[Cr], v40, v59, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v40, v60, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v40, v61, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 1b\n\t"
+        "3:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_sub_f32 v40, v42, %[fpx]\n\t"
+        "v_sub_f32 v41, v43, %[fpy]\n\t"
+        "v_mul_f32 v62, v44, v40\n\t"
+        "v_fma_f32 v62, v45, v41, v62\n\t"
+        "v_mul_f32 v63, v46, v41\n\t"
+        "v_fma_f32 v63, v63, v41, v48\n\t"
+        "v_fma_f32 v62, v40, v62, v63\n\t"
+        "v_exp_f32 v63, v62\n\t"
+        "v_cmpx_le_f32 vcc, v62, v48\n\t"
+        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[T], v63\n\t"
+        "v_fma_f32 %[Cr], v40, v49, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v40, v50, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v40, v51, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 5f\n\t"
+        "4:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_sub_f32 v40, v52, %[fpx]\n\t"
+        "v_sub_f32 v41, v53, %[fpy]\n\t"
+        "v_mul_f32 v62, v54, v40\n\t"
+        "v_fma_f32 v62, v55, v41, v62\n\t"
+        "v_mul_f32 v63, v56, v41\n\t"
+        "v_fma_f32 v63, v63, v41, v58\n\t"
+        "v_fma_f32 v62, v40, v62, v63\n\t"
+        "v_exp_f32 v63, v62\n\t"
+        "v_cmpx_le_f32 vcc, v62, v58\n\t"
+        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[T], v63\n\t"
+        "v_fma_f32 %[Cr], v40, v59, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v40, v60, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v40, v61, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "5:\n\t"
+        : [T] "+v"(T), [Cr] "+v"(Cr), [Cg] "+v"(Cg), [Cb] "+v"(Cb), [m] "+s"(m), [idx] "=&s"(idx)
+        : [base] "v"(lds_chunk), [fpx] "v"(fpx), [fpy] "v"(fpy)
+        : "vcc", "scc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",
+          "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 }
 
 // Tile launch order.  Group g = tile rows g, g+8, ... of the shard (one XCD's share).  One workgroup per
@@ -176,12 +238,12 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict
     }
 }
 
-template <bool MASKED, int DBG = 0>
+template <bool ASM_WALK>
 __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
 {
-    __shared__ float4 s0[256];
-    __shared__ float4 s1[256];
-    __shared__ float4 s2[256];
+    __shared__ float4 srec[3][256];  // staged records, one plane per 16-B part: q0 at +0, q1 at +4096, q2 at +8192 bytes
+    float4 *const s0 = srec[0], *const s1 = srec[1], *const s2 = srec[2];
+    const unsigned lds_rec = (unsigned)(size_t)&srec[0][0];  // LDS byte address: the low half of the flat pointer
     __shared__ int s_done;
 
     const int tile = a.order[blockIdx.x];
@@ -224,41 +286,17 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
             const bool hit = e < nb && footprint_hits_rect(s0[e], s1[e], qx0, qx1, qy0, qy1);
             unsigned long long m = __ballot(hit);
             evaluated += (uint32_t)__popcll(m);
-            // Survivor walk: two per trip, so that the second one's LDS broadcast reads overlap the first one's arithmetic.
-            if (MASKED) {
-                // straight-line body: with an odd count the last trip re-reads its survivor and evaluates it with EXEC gated
-                // off (~1 % of the evaluations) — any branch around the second evaluation makes the compiler shuffle T and
-                // the colour sums between registers on every trip (two extra VALU per entry)
-                while (m) {
-                    const int b0 = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const unsigned long long m1 = m;  // survivors left after the first: zero gates the second evaluation off
-                    const int b1 = m1 ? __ffsll((long long)m1) - 1 : b0;
-                    m &= m - 1;
-                    const int k0 = chunk + b0, k1 = chunk + b1;
-                    const float2 ga = *reinterpret_cast<const float2 *>(&s0[k0]);  // wave-uniform address: LDS broadcast
-                    const float4 ca = s1[k0];
-                    const float4 oa = s2[k0];
-                    const float2 gb = *reinterpret_cast<const float2 *>(&s0[k1]);
-                    const float4 cb = s1[k1];
-                    const float4 ob = s2[k1];
-                    if (DBG == 4) {
-                        asm volatile("" ::"v"(ca.w), "v"(cb.w));
-                        blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
-                        if (m1) blend_one(gb, cb, ob, fpx, fpy, T, Cr, Cg, Cb);
-                    } else {
-                    blend_one_x(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
-                    blend_one_xg(gb, cb, ob, fpx, fpy, T, Cr, Cg, Cb, m1);
-                    }
-                }
+            if (ASM_WALK) {
+                if (m) blend_walk_asm(m, lds_rec + (unsigned)chunk * 16u, fpx, fpy, T, Cr, Cg, Cb);
             } else {
+                // plain form: two survivors per trip so that the second one's LDS reads overlap the first one's arithmetic
                 while (m) {
                     const int k0 = chunk + (__ffsll((long long)m) - 1);
                     m &= m - 1;
-                    const float2 ga = *reinterpret_cast<const float2 *>(&s0[k0]);
+                    const float2 ga = *reinterpret_cast<const float2 *>(&s0[k0]);  // wave-uniform address: LDS broadcast
                     const float4 ca = s1[k0];
                     const float4 oa = s2[k0];
-                    asm volatile("" ::"v"(ca.w));
+                    asm volatile("" ::"v"(ca.w));  // keep the read a ds_read_b128 (4 LDS cycles); a b96 costs 8
                     if (m) {
                         const int k1 = chunk + (__ffsll((long long)m) - 1);
                         m &= m - 1;
@@ -266,11 +304,10 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
                         const float4 cb = s1[k1];
                         const float4 ob = s2[k1];
                         asm volatile("" ::"v"(cb.w));
-                        if (DBG == 5) { blend_one_x(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb); blend_one_x(gb, cb, ob, fpx, fpy, T, Cr, Cg, Cb); }
-                        else { blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb); blend_one(gb, cb, ob, fpx, fpy, T, Cr, Cg, Cb); }
+                        blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
+                        blend_one(gb, cb, ob, fpx, fpy, T, Cr, Cg, Cb);
                     } else {
-                        if (DBG == 5) blend_one_x(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
-                        else blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
+                        blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
                     }
                 }
             }
@@ -297,119 +334,6 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
                             : a.layout == 0 ? (size_t)py * a.W + px
                                             : (size_t)(((ty - a.row_begin) / a.row_step) * 16 + (py - ty * 16)) * a.W + px;
             a.out_T[ot] = drawn ? T : 1.0f;
-        }
-    }
-}
-
-// Half-tile variant (GsrOptions.blend_impl = 3): one 128-thread workgroup per 16x16 tile, wave w = the 16x8 half (pixel rows
-// 8w .. 8w+7), a lane = TWO pixels 8 columns apart, one in each 8x8 quadrant of the half.  Same lists, same per-quadrant
-// culling and saturation tests, same per-pixel arithmetic in the same order as blend_kernel — frames are bit-identical — but
-// an entry that touches both quadrants of a half is read from LDS once instead of twice and walked by the scalar loop once:
-// the LDS pipe (three broadcast reads = 10 LDS cycles per evaluated (wave, entry)) is what blend_kernel saturates together
-// with VALU issue.
-__global__ __launch_bounds__(128) void blend_half_kernel(BlendArgs a)
-{
-    constexpr int BATCH = 128;
-    __shared__ float4 s0[BATCH];
-    __shared__ float4 s1[BATCH];
-    __shared__ float4 s2[BATCH];
-    __shared__ int s_done;
-
-    const int tile = a.order[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t *stat = a.stats + (size_t)blockIdx.x * BLEND_STAT_WORDS;
-    if (tile < 0) {  // uniform: empty launch slot
-        if (tid < 5) stat[tid] = 0;
-        return;
-    }
-    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int qx = tx * 16, qy = ty * 16 + wave * 8;
-    const int px = qx + (lane & 7), py = qy + (lane >> 3);  // pixel A; pixel B = (px + 8, py)
-    const float fpxA = (float)px, fpxB = (float)(px + 8), fpy = (float)py;
-    const float xa0 = (float)qx, xa1 = (float)(qx + 7), xb0 = (float)(qx + 8), xb1 = (float)(qx + 15);
-    const float qy0 = (float)qy, qy1 = (float)(qy + 7);
-
-    const uint2 range = a.ranges[tile];
-    float TA = 1.0f, CrA = 0.0f, CgA = 0.0f, CbA = 0.0f;
-    float TB = 1.0f, CrB = 0.0f, CgB = 0.0f, CbB = 0.0f;
-    bool doneA = false, doneB = false;  // wave-uniform: quadrant saturated
-    uint32_t evaluated = 0;             // wave-uniform
-    uint32_t fetched = 0;               // workgroup-uniform
-    if (tid == 0) s_done = 0;
-
-    for (uint32_t batch = range.x; batch < range.y; batch += BATCH) {
-        __syncthreads();  // previous batch fully consumed (and s_done initialised)
-        if (s_done == 2) break;  // uniform: both waves saturated
-        const uint32_t i = batch + tid;
-        fetched += min((uint32_t)BATCH, range.y - batch);
-        if (i < range.y) {
-            const GaussRec *r = a.rec + a.pval[i];
-            s0[tid] = r->q0;
-            s1[tid] = r->q1;
-            s2[tid] = r->q2;
-        }
-        __syncthreads();
-        if (doneA && doneB) continue;
-        const int nb = min((uint32_t)BATCH, range.y - batch);
-        for (int chunk = 0; chunk < nb; chunk += 64) {
-            const int e = chunk + lane;
-            bool hitA = false, hitB = false;
-            if (e < nb) {
-                const float4 q0 = s0[e], q1 = s1[e];
-                hitA = !doneA && footprint_hits_rect(q0, q1, xa0, xa1, qy0, qy1);
-                hitB = !doneB && footprint_hits_rect(q0, q1, xb0, xb1, qy0, qy1);
-            }
-            const unsigned long long mA = __ballot(hitA), mB = __ballot(hitB);
-            evaluated += (uint32_t)__popcll(mA) + (uint32_t)__popcll(mB);
-            unsigned long long m = mA | mB;
-            while (m) {
-                const int b0 = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const int k0 = chunk + b0;
-                const float2 ga = *reinterpret_cast<const float2 *>(&s0[k0]);  // wave-uniform address: LDS broadcast
-                const float4 ca = s1[k0];
-                const float4 oa = s2[k0];
-                asm volatile("" ::"v"(ca.w));  // keep the read a ds_read_b128 (4 LDS cycles); a b96 costs 8
-                if (m) {  // second survivor: its LDS reads are issued before the first one's arithmetic
-                    const int b1 = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const int k1 = chunk + b1;
-                    const float2 gb = *reinterpret_cast<const float2 *>(&s0[k1]);
-                    const float4 cb = s1[k1];
-                    const float4 ob = s2[k1];
-                    asm volatile("" ::"v"(cb.w));
-                    if ((mA >> b0) & 1ull) blend_one(ga, ca, oa, fpxA, fpy, TA, CrA, CgA, CbA);
-                    if ((mB >> b0) & 1ull) blend_one(ga, ca, oa, fpxB, fpy, TB, CrB, CgB, CbB);
-                    if ((mA >> b1) & 1ull) blend_one(gb, cb, ob, fpxA, fpy, TA, CrA, CgA, CbA);
-                    if ((mB >> b1) & 1ull) blend_one(gb, cb, ob, fpxB, fpy, TB, CrB, CgB, CbB);
-                } else {
-                    if ((mA >> b0) & 1ull) blend_one(ga, ca, oa, fpxA, fpy, TA, CrA, CgA, CbA);
-                    if ((mB >> b0) & 1ull) blend_one(ga, ca, oa, fpxB, fpy, TB, CrB, CgB, CbB);
-                }
-            }
-            if (!doneA && __all(TA <= a.early_T)) doneA = true;
-            if (!doneB && __all(TB <= a.early_T)) doneB = true;
-            if (doneA && doneB) {
-                if (lane == 0) atomicAdd(&s_done, 1);
-                break;
-            }
-        }
-    }
-
-    if (lane == 0) { stat[wave] = evaluated; stat[2 + wave] = 0; }
-    if (tid == 0) stat[4] = fetched;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int x = px + 8 * h;
-        const float T = h ? TB : TA, Cr = h ? CrB : CrA, Cg = h ? CgB : CgA, Cb = h ? CbB : CbA;
-        if (x < a.W && py < a.H) {
-            const bool drawn = x < a.xlim && py < a.ylim;  // Q1: last column / row stay black, T stays 1
-            const float r = drawn ? Cr : 0.0f, g = drawn ? Cg : 0.0f, b = drawn ? Cb : 0.0f;
-            const size_t pix = a.layout == 0 ? (size_t)py * a.W + x                                           // image [H,W,3]
-                             : a.layout == 1 ? (size_t)x * a.H + py                                           // screen [W,H,3]
-                                             : (size_t)(((ty - a.row_begin) / a.row_step) * 16 + (py - ty * 16)) * a.W + x;  // strip
-            store_rgb(a, pix * 3, r, g, b);
-            if (a.out_T) a.out_T[pix] = drawn ? T : 1.0f;
         }
     }
 }
@@ -442,10 +366,7 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
                        slots_per_group, ws.tile_order,
                        (uint32_t)(reinterpret_cast<const char *>(ws.blend_stats) - reinterpret_cast<const char *>(ws.ctrl)));
     if (opts.blend_impl == 2) return launch_blend_mfma(a, 8u * (unsigned)slots_per_group, s);
-    if (opts.blend_impl == 3) hipLaunchKernelGGL(blend_half_kernel, dim3(8u * (unsigned)slots_per_group), dim3(128), 0, s, a);
-    else if (opts.blend_impl == 4) hipLaunchKernelGGL((blend_kernel<true, 4>), dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
-    else if (opts.blend_impl == 5) hipLaunchKernelGGL((blend_kernel<false, 5>), dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
-    else if (opts.blend_impl == 1) hipLaunchKernelGGL(blend_kernel<false>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
+    if (opts.blend_impl == 1) hipLaunchKernelGGL(blend_kernel<false>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(blend_kernel<true>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
