@@ -8,16 +8,17 @@ import gsr_amd
 from gsr_amd import renderer, synthetic, utils, dist as gdist
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_834_784
+only = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else None   # "G r": just this shard (for a rocprofv3 timeline)
 W, H = 1920, 1080
 cols = synthetic.mip360_like(n, 360)
 p = synthetic.ring_cameras(25)[0]
 fx = synthetic.pinhole_focal(W)
 cam = renderer.make_camera(p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H)
 scene = renderer.GaussianScene.from_columns(cols)
-for G in (1, 2, 4, 8):
+for G in (1, 2, 4, 8) if only is None else (only[0],):
     plan = gdist.TileRowPlan(H, W, G)
     times, vis, pairs = [], [], []
-    for r in range(G):
+    for r in range(G) if only is None else (only[1],):
         R = renderer.Rasterizer(scene)
         opts = renderer.make_options(**plan.shard_options(r)) if G > 1 else renderer.make_options()
         R.fit_pairs(cam, opts)

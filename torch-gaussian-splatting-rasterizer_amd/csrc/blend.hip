@@ -69,34 +69,36 @@ __device__ __forceinline__ void blend_one(const float2 g, const float4 c, const 
 //   - the walk itself costs 5 scalar instructions per survivor (s_ff1 + s_bitset0 pop, loop test, EXEC restore) instead of the
 //     compiler's 10.8 (64-bit m & (m - 1) as add/addc/and, address shifts, selects), and the accumulators never change
 //     registers (the compiler's one-or-two-per-trip loop copied T and the colour sums on every trip: 2 VALU per entry).
+//   - survivors flagged `fast` by the culling lane (footprint_classify: neither the 0.99 clamp nor the `p <= L` test can fire
+//     anywhere on this wave's quadrant) take an evaluation without v_min and the second v_cmpx: 15 instead of 17 VALU;
 //   - records roll through two register sets: while survivor k is evaluated the reads of survivor k+1 are in flight (counted
 //     waits: LDS returns in order; the lgkmcnt(0) up front retires anything older, scalar loads included, which do not).
 // Registers v40-v63 are named explicitly (an asm statement takes at most 30 operands): v40/v41 addresses then temporaries,
 // v42-v51 and v52-v61 the two records, v62/v63 temporaries; the kernel stays at 64 VGPRs = 8 waves per SIMD.
-// Measured on the bench frame (interleaved A/B in one process): 0.662 ms against 0.744 ms for the plain kernel; PMC: VALU
-// 21.4 -> 17.6, SALU 9.2 -> 5 instructions per evaluated (quadrant, entry).  Variants that did not pay: two quadrants per
+// Measured on the garden frame (tools/blend_ab.py, interleaved A/B in one process): 0.606 ms against 0.722 ms for the plain
+// kernel (0.642 ms with every survivor on the guarded path).  Variants that did not pay: two quadrants per
 // wave (16x8 half-tiles, one LDS read for both: +4 %, the LDS pipe is not the limit); skipping the pass of an empty 32-lane
 // EXEC half (the hardware does not: 8x4 culling is pointless); the same walk without the rolling prefetch (equal: 8 waves per
 // SIMD already hide the LDS latency).  The text below is generated by tools/gen_blend_walk.py.
 // lds_chunk = LDS byte address of the chunk's first record (plane 0), identical in every lane.
-__device__ __forceinline__ void blend_walk_asm(unsigned long long m, unsigned lds_chunk, float fpx, float fpy, float &T, float &Cr,
-                                               float &Cg, float &Cb)
+__device__ __forceinline__ void blend_walk_asm(unsigned long long m, unsigned long long fast, unsigned lds_chunk, float fpx, float fpy,
+                                               float &T, float &Cr, float &Cg, float &Cb)
 {
-    int idx;
+    int ia, ib;
     asm volatile(
         "s_waitcnt lgkmcnt(0)\n\t"
-        "s_ff1_i32_b64 %[idx], %[m]\n\t"
-        "s_bitset0_b64 %[m], %[idx]\n\t"
-        "v_lshl_add_u32 v40, %[idx], 4, %[base]\n\t"
+        "s_ff1_i32_b64 %[ia], %[m]\n\t"
+        "s_bitset0_b64 %[m], %[ia]\n\t"
+        "v_lshl_add_u32 v40, %[ia], 4, %[base]\n\t"
         "ds_read_b64 v[42:43], v40\n\t"
         "ds_read_b128 v[44:47], v40 offset:4096\n\t"
         "ds_read_b128 v[48:51], v40 offset:8192\n\t"
         "1:\n\t"
         "s_cmp_eq_u64 %[m], 0\n\t"
         "s_cbranch_scc1 3f\n\t"
-        "s_ff1_i32_b64 %[idx], %[m]\n\t"
-        "s_bitset0_b64 %[m], %[idx]\n\t"
-        "v_lshl_add_u32 v41, %[idx], 4, %[base]\n\t"
+        "s_ff1_i32_b64 %[ib], %[m]\n\t"
+        "s_bitset0_b64 %[m], %[ib]\n\t"
+        "v_lshl_add_u32 v41, %[ib], 4, %[base]\n\t"
         "ds_read_b64 v[52:53], v41\n\t"
         "ds_read_b128 v[54:57], v41 offset:4096\n\t"
         "ds_read_b128 v[58:61], v41 offset:8192\n\t"
@@ -109,6 +111,8 @@ __device__ __forceinline__ void blend_walk_asm(unsigned long long m, unsigned ld
         "v_fma_f32 v63, v63, v41, v48\n\t"
         "v_fma_f32 v62, v40, v62, v63\n\t"
         "v_exp_f32 v63, v62\n\t"
+        "s_bitcmp1_b64 %[fast], %[ia]\n\t"
+        "s_cbranch_scc1 10f\n\t"
         "v_cmpx_le_f32 vcc, v62, v48\n\t"
         "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
@@ -118,11 +122,22 @@ __device__ __forceinline__ void blend_walk_asm(unsigned long long m, unsigned ld
         "v_fma_f32 %[Cb], v40, v51, %[Cb]\n\t"
         "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
         "s_mov_b64 exec, -1\n\t"
+        "s_branch 11f\n\t"
+        "10:\n\t"
+        "s_nop 0\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[T], v63\n\t"
+        "v_fma_f32 %[Cr], v40, v49, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v40, v50, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v40, v51, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "11:\n\t"
         "s_cmp_eq_u64 %[m], 0\n\t"
         "s_cbranch_scc1 4f\n\t"
-        "s_ff1_i32_b64 %[idx], %[m]\n\t"
-        "s_bitset0_b64 %[m], %[idx]\n\t"
-        "v_lshl_add_u32 v40, %[idx], 4, %[base]\n\t"
+        "s_ff1_i32_b64 %[ia], %[m]\n\t"
+        "s_bitset0_b64 %[m], %[ia]\n\t"
+        "v_lshl_add_u32 v40, %[ia], 4, %[base]\n\t"
         "ds_read_b64 v[42:43], v40\n\t"
         "ds_read_b128 v[44:47], v40 offset:4096\n\t"
         "ds_read_b128 v[48:51], v40 offset:8192\n\t"
@@ -135,6 +150,8 @@ __device__ __forceinline__ void blend_walk_asm(unsigned long long m, unsigned ld
         "v_fma_f32 v63, v63, v41, v58\n\t"
         "v_fma_f32 v62, v40, v62, v63\n\t"
         "v_exp_f32 v63, v62\n\t"
+        "s_bitcmp1_b64 %[fast], %[ib]\n\t"
+        "s_cbranch_scc1 12f\n\t"
         "v_cmpx_le_f32 vcc, v62, v58\n\t"
         "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
@@ -144,6 +161,17 @@ __device__ __forceinline__ void blend_walk_asm(unsigned long long m, unsigned ld
         "v_fma_f32 %[Cb], v40, v61, %[Cb]\n\t"
         "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
         "s_mov_b64 exec, -1\n\t"
+        "s_branch 13f\n\t"
+        "12:\n\t"
+        "s_nop 0\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[T], v63\n\t"
+        "v_fma_f32 %[Cr], v40, v59, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v40, v60, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v40, v61, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "13:\n\t"
         "s_branch 1b\n\t"
         "3:\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
@@ -155,6 +183,8 @@ __device__ __forceinline__ void blend_walk_asm(unsigned long long m, unsigned ld
         "v_fma_f32 v63, v63, v41, v48\n\t"
         "v_fma_f32 v62, v40, v62, v63\n\t"
         "v_exp_f32 v63, v62\n\t"
+        "s_bitcmp1_b64 %[fast], %[ia]\n\t"
+        "s_cbranch_scc1 14f\n\t"
         "v_cmpx_le_f32 vcc, v62, v48\n\t"
         "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
@@ -164,6 +194,17 @@ __device__ __forceinline__ void blend_walk_asm(unsigned long long m, unsigned ld
         "v_fma_f32 %[Cb], v40, v51, %[Cb]\n\t"
         "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
         "s_mov_b64 exec, -1\n\t"
+        "s_branch 15f\n\t"
+        "14:\n\t"
+        "s_nop 0\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[T], v63\n\t"
+        "v_fma_f32 %[Cr], v40, v49, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v40, v50, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v40, v51, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "15:\n\t"
         "s_branch 5f\n\t"
         "4:\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
@@ -175,6 +216,8 @@ __device__ __forceinline__ void blend_walk_asm(unsigned long long m, unsigned ld
         "v_fma_f32 v63, v63, v41, v58\n\t"
         "v_fma_f32 v62, v40, v62, v63\n\t"
         "v_exp_f32 v63, v62\n\t"
+        "s_bitcmp1_b64 %[fast], %[ib]\n\t"
+        "s_cbranch_scc1 16f\n\t"
         "v_cmpx_le_f32 vcc, v62, v58\n\t"
         "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
@@ -184,9 +227,20 @@ __device__ __forceinline__ void blend_walk_asm(unsigned long long m, unsigned ld
         "v_fma_f32 %[Cb], v40, v61, %[Cb]\n\t"
         "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
         "s_mov_b64 exec, -1\n\t"
+        "s_branch 17f\n\t"
+        "16:\n\t"
+        "s_nop 0\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[T], v63\n\t"
+        "v_fma_f32 %[Cr], v40, v59, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v40, v60, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v40, v61, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "17:\n\t"
         "5:\n\t"
-        : [T] "+v"(T), [Cr] "+v"(Cr), [Cg] "+v"(Cg), [Cb] "+v"(Cb), [m] "+s"(m), [idx] "=&s"(idx)
-        : [base] "v"(lds_chunk), [fpx] "v"(fpx), [fpy] "v"(fpy)
+        : [T] "+v"(T), [Cr] "+v"(Cr), [Cg] "+v"(Cg), [Cb] "+v"(Cb), [m] "+s"(m), [ia] "=&s"(ia), [ib] "=&s"(ib)
+        : [base] "v"(lds_chunk), [fpx] "v"(fpx), [fpy] "v"(fpy), [fast] "s"(fast)
         : "vcc", "scc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",
           "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 }
@@ -283,11 +337,19 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
         const int nb = min(256u, range.y - batch);
         for (int chunk = 0; chunk < nb; chunk += 64) {
             const int e = chunk + lane;
-            const bool hit = e < nb && footprint_hits_rect(s0[e], s1[e], qx0, qx1, qy0, qy1);
-            unsigned long long m = __ballot(hit);
+            unsigned long long m, fast = 0;
+            if (ASM_WALK) {
+                FootprintClass fc = {false, false};
+                if (e < nb) fc = footprint_classify(s0[e], s1[e], s2[e].x, qx0, qx1, qy0, qy1);
+                m = __ballot(fc.hit);
+                fast = __ballot(fc.fast);
+            } else {
+                const bool hit = e < nb && footprint_hits_rect(s0[e], s1[e], qx0, qx1, qy0, qy1);
+                m = __ballot(hit);
+            }
             evaluated += (uint32_t)__popcll(m);
             if (ASM_WALK) {
-                if (m) blend_walk_asm(m, lds_rec + (unsigned)chunk * 16u, fpx, fpy, T, Cr, Cg, Cb);
+                if (m) blend_walk_asm(m, fast, lds_rec + (unsigned)chunk * 16u, fpx, fpy, T, Cr, Cg, Cb);
             } else {
                 // plain form: two survivors per trip so that the second one's LDS reads overlap the first one's arithmetic
                 while (m) {
