@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Condense a gpurun_out/prof_* directory (rocprofv3 csv output) into the small, judged files under profiles/.
 
-usage: tools/summarize_profiles.py gpurun_out/prof_r1 profiles/r1
+usage: tools/summarize_profiles.py gpurun_out/prof_r2 profiles/r2 [workload]
 writes <out>_kernel_stats.csv (the --stats summary, verbatim), <out>_frame_timeline.txt, <out>_pmc.json and
-updates profiles/pmc_traffic.json (per-launch HBM traffic of the blend kernel, read by bench.py).
+updates profiles/pmc_traffic.json (per-launch HBM traffic and pipe figures of the blend kernel for that workload, read by
+bench.py).
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE
 tallies 128-B requests at 64 B, i.e. reads come out at one half for wide coalesced streams — the corrected figure
@@ -21,6 +22,7 @@ import sys
 
 def main():
     src, out = sys.argv[1], sys.argv[2]
+    workload = sys.argv[3] if len(sys.argv) > 3 else "bicycle"
     os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
     shutil.copy(os.path.join(src, "trace_kernel_stats.csv"), out + "_kernel_stats.csv")
     tl = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "frame_timeline.py"),
@@ -30,7 +32,7 @@ def main():
     for f in sorted(glob.glob(os.path.join(src, "pmc_*_counter_collection.csv"))):
         per = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            kern = "blend_kernel" if "blend_kernel" in r["Kernel_Name"] else ("preprocess_kernel" if "preprocess_kernel" in r["Kernel_Name"] else r["Kernel_Name"][:40])
+            kern = "blend_kernel" if "blend_kernel<" in r["Kernel_Name"] or "blend_kernel(" in r["Kernel_Name"] else ("preprocess_kernel" if "preprocess_kernel" in r["Kernel_Name"] else r["Kernel_Name"][:40])
             per[kern][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for kern, cs in per.items():
             for c, v in cs.items():
@@ -51,8 +53,30 @@ def main():
     tfile = os.path.join(os.path.dirname(out) or ".", "pmc_traffic.json")
     traffic = json.load(open(tfile)) if os.path.exists(tfile) else {}
     if "blend_kernel" in derived and "hbm_bytes_per_launch" in derived["blend_kernel"]:
-        traffic.setdefault("garden", {})["blend_kernel_bytes_per_launch"] = derived["blend_kernel"]["hbm_bytes_per_launch"]
-        traffic["garden"]["source"] = os.path.basename(out) + "_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+        t = traffic.setdefault(workload, {})
+        t["blend_kernel_bytes_per_launch"] = derived["blend_kernel"]["hbm_bytes_per_launch"]
+        t["source"] = os.path.basename(out) + "_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+        c = {k: v["per_launch_mean"] for k, v in pmc["blend_kernel"].items()}
+        try:  # pipe figures: per evaluated (quadrant, entry) instruction counts need the frame's counter from the traced bench
+            we = json.load(open(os.path.join(src, "bench_under_trace.json")))["stats"]["wave_entries"]
+            t["wave_entries"] = we
+            if "SQ_INSTS_VALU" in c:
+                t["valu_insts_per_wave_entry"] = c["SQ_INSTS_VALU"] / we
+            if "SQ_INSTS_SALU" in c:
+                t["salu_insts_per_wave_entry"] = c["SQ_INSTS_SALU"] / we
+        except Exception as e:  # noqa: BLE001
+            print("no per-entry figures:", e)
+        if "GRBM_GUI_ACTIVE" in c:
+            cyc = c["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+            rows = [r for r in csv.DictReader(open(out + "_kernel_stats.csv")) if "blend_kernel" in r["Name"]]
+            if rows:
+                t["clock_ghz"] = cyc / float(rows[0]["AverageNs"])
+            if "SQ_LDS_IDX_ACTIVE" in c:
+                t["lds_busy_frac"] = c["SQ_LDS_IDX_ACTIVE"] / 256.0 / cyc  # LDS-array cycles per CU over the kernel's cycles
+            if "SQ_INSTS_SALU" in c:
+                t["salu_issue_frac"] = c["SQ_INSTS_SALU"] / 256.0 / cyc  # one scalar unit per CU
+            if "SQ_INSTS_VALU" in c:
+                t["valu_issue_frac_2cyc"] = c["SQ_INSTS_VALU"] * 2.0 / 1024.0 / cyc  # at the 2-cycle floor of a wave64 VALU op
     json.dump(traffic, open(tfile, "w"), indent=1)
     print(tl)
     print(json.dumps(derived, indent=1))
