@@ -102,8 +102,9 @@ typedef struct GsrOptions {
 /* Counters of one frame (device -> host with gsr_read_stats). */
 typedef struct GsrStats {
     uint32_t n_visible;     /* V: gaussians that survive cull and have a non-empty footprint */
-    uint32_t n_pairs_bbox;  /* D: (gaussian,tile) pairs of the visible gaussians' tile rects (this shard) */
-    uint32_t n_pairs;       /* E: pairs actually sorted and consumed by the blend (after footprint culling) */
+    uint32_t n_pairs_bbox;  /* D: pair slots this frame needs, i.e. what max_pairs must cover: (gaussian, 32x32 cell) pairs of the
+                               visible gaussians' rects (frames wider than 4096 px: (gaussian, 16x16 tile) pairs of this shard) */
+    uint32_t n_pairs;       /* E: entries of the per-tile lists the blend consumes (this shard; after footprint culling) */
     uint32_t overflow;      /* 1 if D exceeded max_pairs (frame incomplete) */
     uint32_t max_list_len;  /* longest per-tile list */
     uint32_t _pad;

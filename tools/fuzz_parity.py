@@ -92,6 +92,12 @@ def main():
             assert torch.equal(R.render(cam), img), "not reproducible"
             assert torch.equal(R.render(cam, mk(no_footprint_cull=True)), img), "culling changes bits"
             assert torch.equal(R.render(cam, mk(blend_impl=1)), img), "asm walk differs from the plain blend kernel"
+            os.environ["GSR_FINE_BINNING"] = "1"
+            try:
+                fine = R.render(cam)
+            finally:
+                del os.environ["GSR_FINE_BINNING"]
+            assert torch.equal(fine, img), "coarse and fine binning differ"
             assert torch.equal(R.render(cam, mk(output_bf16=True)), img.to(torch.bfloat16)), "bf16 store"
             step = int(rng.choice([2, 3, 5, 8]))
             tiles_y = (H + 15) // 16

@@ -42,6 +42,8 @@ size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max
     ws->max_pairs = max_pairs;
     ws->tiles_x = (width + GSR_TILE - 1) / GSR_TILE;
     ws->tiles_y = (height + GSR_TILE - 1) / GSR_TILE;
+    ws->ctiles_x = (ws->tiles_x + 1) / 2;
+    ws->ctiles_y = (ws->tiles_y + 1) / 2;
     // row stride of the histogram table: tiles of the depth sort, tiles of the pair sort
     ws->hist_blocks = (int)std::max((nn + DEPTH_SORT_THREADS * DEPTH_SORT_ITEMS - 1) / (DEPTH_SORT_THREADS * DEPTH_SORT_ITEMS),
                                     (np + PAIR_SORT_THREADS * PAIR_SORT_ITEMS - 1) / (PAIR_SORT_THREADS * PAIR_SORT_ITEMS));
@@ -57,6 +59,8 @@ size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max
     for (int b = 0; b < 2; ++b) ws->pkey[b] = static_cast<uint32_t *>(take(4 * np));
     for (int b = 0; b < 2; ++b) ws->pval[b] = static_cast<uint32_t *>(take(4 * np));
     ws->ranges = static_cast<uint2 *>(take(sizeof(uint2) * (size_t)ws->tiles_x * ws->tiles_y));
+    ws->cranges = static_cast<uint2 *>(take(sizeof(uint2) * (size_t)ws->ctiles_x * ws->ctiles_y));
+    ws->pexp = static_cast<uint32_t *>(take(4 * 4 * np));
     const size_t order_slots = 8 * (size_t)((ws->tiles_y + 7) / 8) * ws->tiles_x;
     ws->tile_order = static_cast<int *>(take(sizeof(int) * order_slots));
     ws->blend_stats = static_cast<uint32_t *>(take(sizeof(uint32_t) * BLEND_STAT_WORDS * order_slots));
@@ -241,11 +245,8 @@ int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_
     // depth order: pass 0 drops culled gaussians and leaves V in ctrl; 3 passes on ordinary scenes (sort.hip)
     rc = launch_depth_sort(ws, rect_fits_8bit(ws), s);
     if (rc) return rc;
-    // pairs in depth order, stably sorted by tile; E in ctrl
-    int pbuf = 0;
-    rc = launch_binning(*opts, ws, &pbuf, s);
-    if (rc) return rc;
-    return launch_tile_ranges(ws, pbuf, s);
+    // pairs in depth order, stably sorted by tile -> per-tile lists and their ranges; E in ctrl
+    return launch_binning(*opts, ws, s);
 }
 
 int gsr_blend(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs, void *workspace,
@@ -255,7 +256,7 @@ int gsr_blend(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t m
     Workspace ws;
     int rc = check_frame(n, cam, opts, max_pairs, workspace, workspace_bytes, &ws);
     if (rc) return rc;
-    return launch_blend(*cam, *opts, ws, pair_result_buf(ws), out_image, out_final_T, static_cast<hipStream_t>(stream));
+    return launch_blend(*cam, *opts, ws, tile_lists(ws), out_image, out_final_T, static_cast<hipStream_t>(stream));
 }
 
 static int render_forward_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,

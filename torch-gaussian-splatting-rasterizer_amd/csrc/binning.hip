@@ -25,6 +25,7 @@
 // histogram kernel and one write + two reads of the pair arrays, but a workgroup then walks its rounds serially with
 // rounds 69 % full and 3 instead of 4 workgroups per CU — 245 us against 149 us for emit + histogram + scatter.
 // Roofline: HBM.  Bytes: 8 B per sorted gaussian (id + rect) + 8 B per pair written; ranges reads 4 B per pair.
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include "gsr_internal.h"
@@ -67,6 +68,16 @@ __device__ __forceinline__ ushort4 unpack_rect8(uint32_t r)
                         (unsigned short)((r >> 24) + 1u));
 }
 
+constexpr int COARSE_ID_BITS = 28;  // coarse pairs: value = gaussian id | (mask of the cell's tiles the gaussian reaches) << 28
+
+// tile rect -> rect of the 32x32 cells (2x2 tiles) it touches; an empty rect stays empty
+__device__ __forceinline__ ushort4 coarse_rect(ushort4 rc)
+{
+    if (rc.z <= rc.x || rc.w <= rc.y) return make_ushort4(0, 0, 0, 0);
+    return make_ushort4((unsigned short)(rc.x >> 1), (unsigned short)(rc.y >> 1), (unsigned short)(((rc.z - 1) >> 1) + 1),
+                        (unsigned short)(((rc.w - 1) >> 1) + 1));
+}
+
 // k-th tile of a rect of width w in row-major order -> (row, col).  k < 2^24: float division is exact up to the fix-up.
 __device__ __forceinline__ void row_col(uint32_t k, uint32_t w, uint32_t *row, uint32_t *col)
 {
@@ -77,21 +88,28 @@ __device__ __forceinline__ void row_col(uint32_t k, uint32_t w, uint32_t *row, u
     *col = k - r * w;
 }
 
-template <bool PACKED>
+template <bool PACKED, bool COARSE>
 __device__ __forceinline__ ushort4 rect_of(uint32_t r, const uint32_t *sorted_ids, const uint32_t *sorted_rect8, const ushort4 *rect)
 {
-    return PACKED ? unpack_rect8(sorted_rect8[r]) : rect[sorted_ids[r]];
+    const ushort4 rc = PACKED ? unpack_rect8(sorted_rect8[r]) : rect[sorted_ids[r]];
+    return COARSE ? coarse_rect(rc) : rc;
 }
 
-template <bool PACKED>
+template <bool PACKED, bool COARSE>
 __global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t *__restrict__ id_a, const uint32_t *__restrict__ id_b,
                                                                   const uint32_t *__restrict__ r8_a, const uint32_t *__restrict__ r8_b,
                                                                   const FrameCtrl *ctrl, const ushort4 *__restrict__ rect, Shard sh,
                                                                   uint32_t *__restrict__ blk_sum, uint2 *__restrict__ ranges,
-                                                                  int n_tiles, uint32_t draw_limit)
+                                                                  int n_tiles, uint32_t draw_limit, uint2 *__restrict__ cranges, int n_ctiles,
+                                                                  FrameCtrl *ctrl_w)
 {
     __shared__ uint32_t scratch[8];
     const uint32_t n = ctrl->n_visible;
+    if (COARSE) {  // the cell ranges are rebuilt every frame too, and the expansion totals E with atomics
+        const uint32_t t = blockIdx.x * EMIT_THREADS + threadIdx.x;
+        if (t < (uint32_t)n_ctiles) cranges[t] = make_uint2(0u, 0u);
+        if (t == 0) ctrl_w->n_pairs = 0u;
+    }
     const bool odd = (ctrl->sort_passes & 1u) != 0;
     const uint32_t *sorted_ids = odd ? id_b : id_a, *sorted_rect8 = odd ? r8_b : r8_a;
     const uint32_t r = blockIdx.x * EMIT_THREADS + threadIdx.x;
@@ -99,7 +117,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t
     uint32_t cnt = 0;
     if (r < n && r < draw_limit) {  // r = rank in the draw order
         int first;
-        cnt = tiles_of(rect_of<PACKED>(r, sorted_ids, sorted_rect8, rect), sh, &first);
+        cnt = tiles_of(rect_of<PACKED, COARSE>(r, sorted_ids, sorted_rect8, rect), sh, &first);
     }
     uint32_t total;
     block_excl_scan_256(cnt, scratch, &total);
@@ -178,7 +196,7 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(uint32_t *__restrict__ 
 // Load-balanced expansion in emission order: a workgroup owns 256 consecutive gaussians and the contiguous slot range
 // their pairs occupy; every thread takes slots j, j+256, ..., finds the owning gaussian by binary search over the
 // workgroup's 256 offsets in LDS and writes (tile key, gaussian id) — coalesced stores however heavy-tailed the rects are.
-template <bool PACKED>
+template <bool PACKED, bool COARSE>
 __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t *__restrict__ id_a, const uint32_t *__restrict__ id_b,
                                                                  const uint32_t *__restrict__ r8_a, const uint32_t *__restrict__ r8_b,
                                                                  const FrameCtrl *ctrl, const ushort4 *__restrict__ rect, Shard sh,
@@ -194,6 +212,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
     __shared__ int s_first[EMIT_THREADS];      // first tile row of the shard, or -1 - first when the rect is culled per tile
     __shared__ float4 s_q0[EMIT_THREADS];
     __shared__ float4 s_q1[EMIT_THREADS];
+    __shared__ uint32_t s_fine[COARSE ? EMIT_THREADS : 1];  // coarse: the gaussian's packed TILE rect
     const uint32_t n = ctrl->n_visible;
     const bool odd = (ctrl->sort_passes & 1u) != 0;
     const uint32_t *sorted_ids = odd ? id_b : id_a, *sorted_rect8 = odd ? r8_b : r8_a;
@@ -205,8 +224,9 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
     ushort4 rc = make_ushort4(0, 0, 0, 0);
     if (r < n && r < draw_limit) {
         g = sorted_ids[r];
-        rc = rect_of<PACKED>(r, sorted_ids, sorted_rect8, rect);
+        rc = rect_of<PACKED, COARSE>(r, sorted_ids, sorted_rect8, rect);
         cnt = tiles_of(rc, sh, &first);
+        if (COARSE) s_fine[tid] = sorted_rect8[r];
     }
     const bool test = cnt > CULL_MIN_TILES;
     if (test) { s_q0[tid] = rec[g].q0; s_q1[tid] = rec[g].q1; }
@@ -234,21 +254,39 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
         const int ty = (tested ? -1 - fr : fr) + (int)row * sh.step, tx = (int)(geo & 0xFFFFu) + (int)col;
         const unsigned long long o = base + j;
         if (o < (unsigned long long)max_pairs) {
-            const bool hit = !tested || footprint_hits_rect(s_q0[lo], s_q1[lo], (float)(tx * 16), (float)(tx * 16 + 15),
-                                                            (float)(ty * 16), (float)(ty * 16 + 15));
-            pkey[o] = (hit ? (uint32_t)ty << bits_x : culled_row) | (uint32_t)tx;
-            pval[o] = s_id[lo];
+            if (COARSE) {
+                // which of the cell's four tiles does the gaussian's tile rect cover?  The mask rides in the top four bits of the
+                // pair value.  Large rects are tested once per cell against the footprint (per tile it costs emit 20 us to
+                // spare the blend 3 % of its staging).
+                const uint32_t f = s_fine[lo];
+                const int x0 = (int)(f & 255u), y0 = (int)((f >> 8) & 255u), x1 = (int)((f >> 16) & 255u), y1 = (int)(f >> 24);  // inclusive
+                uint32_t mask = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int fx = 2 * tx + (q & 1), fy = 2 * ty + (q >> 1);
+                    mask |= (fx >= x0 && fx <= x1 && fy >= y0 && fy <= y1) ? 1u << q : 0u;
+                }
+                const bool hit = !tested || footprint_hits_rect(s_q0[lo], s_q1[lo], (float)(tx * 32), (float)(tx * 32 + 31),
+                                                                (float)(ty * 32), (float)(ty * 32 + 31));
+                pkey[o] = (hit ? (uint32_t)ty << bits_x : culled_row) | (uint32_t)tx;
+                pval[o] = s_id[lo] | mask << COARSE_ID_BITS;
+            } else {
+                const bool hit = !tested || footprint_hits_rect(s_q0[lo], s_q1[lo], (float)(tx * 16), (float)(tx * 16 + 15),
+                                                                (float)(ty * 16), (float)(ty * 16 + 15));
+                pkey[o] = (hit ? (uint32_t)ty << bits_x : culled_row) | (uint32_t)tx;
+                pval[o] = s_id[lo];
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t *__restrict__ pkey, const FrameCtrl *ctrl,
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t *__restrict__ pkey, const uint32_t *n_dev,
                                                           uint2 *__restrict__ ranges, int bits_x, int tiles_x, int n_tiles,
                                                           uint32_t stride)
 {
     // four keys per thread from one 16-B load; only the two keys flanking the group are read a second time.
     // stride = threads in the grid, passed in: gridDim / blockDim would pull in the 256-B hidden kernarg block
-    const uint32_t n = ctrl->n_pairs;
+    const uint32_t n = *n_dev;
     const uint32_t maskx = (1u << bits_x) - 1u;
     for (uint32_t t = blockIdx.x * 256u + threadIdx.x; 4ull * t < n; t += stride) {
         const uint32_t i = 4u * t;
@@ -274,6 +312,76 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t *__rest
     }
 }
 
+// Coarse binning, last step: every 32x32 cell's list (depth-ordered; value = gaussian id | tile mask << 28, the mask set at
+// emission from the gaussian's tile rect and, for large rects, the per-tile footprint test) -> the lists of its four 16x16
+// tiles.  One 1024-thread workgroup per cell, 4096 entries per trip.  An entry goes to tile q iff its mask has bit q and the
+// tile's row belongs to this shard; ballots + a wave scan over the 64 (sub-chunk, wave) counts make the compaction stable, so
+// every tile list is in depth order.  Tile q's list lives at [4 begin + q len, ... + count_q) of `pexp` (begin, len = the
+// cell's range): no global scan, the tile ranges are known on the spot.
+constexpr int EXPAND_THREADS = 1024, EXPAND_PER = 4;
+__global__ __launch_bounds__(EXPAND_THREADS) void pair_expand_kernel(const uint2 *__restrict__ cranges, const uint32_t *__restrict__ cval,
+                                                                     Shard sh, int ctiles_x, int tiles_x, int tiles_y,
+                                                                     uint32_t *__restrict__ pexp, uint2 *__restrict__ ranges, FrameCtrl *ctrl)
+{
+    constexpr int PER = EXPAND_PER, WAVES = EXPAND_THREADS / 64;
+    static_assert(PER * WAVES == 64, "one wave scans the (sub-chunk, wave) counts");
+    __shared__ uint32_t s_cnt[4][PER * WAVES];  // [tile q][sub-chunk j * WAVES + wave]: counts, then exclusive offsets
+    __shared__ uint32_t s_tot[4];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint2 cr = cranges[c];
+    const uint32_t len = cr.y - cr.x;
+    if (len == 0) return;  // uniform
+    const int cy = c / ctiles_x, cx = c - cy * ctiles_x;
+    uint32_t okmask = 0;  // tiles of this cell that exist and belong to the shard
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int tx = 2 * cx + (q & 1), ty = 2 * cy + (q >> 1);
+        if (tx < tiles_x && ty < tiles_y && ty >= sh.begin && (ty - sh.begin) % sh.step == 0) okmask |= 1u << q;
+    }
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t out0 = 4u * cr.x;
+    uint32_t run[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t base = 0; base < len; base += EXPAND_THREADS * PER) {
+        uint32_t v[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t i = base + j * EXPAND_THREADS + tid;
+            v[j] = i < len ? cval[cr.x + i] : 0u;  // mask 0: goes nowhere
+        }
+        unsigned long long b[PER][4];
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                b[j][q] = __ballot(((v[j] >> COARSE_ID_BITS) & okmask) >> q & 1u);
+                if (lane == 0) s_cnt[q][j * WAVES + wave] = (uint32_t)__popcll(b[j][q]);
+            }
+        __syncthreads();
+        if (wave < 4) {  // wave q: exclusive scan of tile q's 64 counts, in list order (sub-chunk, wave)
+            const uint32_t x = s_cnt[wave][lane];
+            const uint32_t incl = wave_incl_scan(x);
+            s_cnt[wave][lane] = incl - x;
+            if (lane == 63) s_tot[wave] = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t dst = out0 + (uint32_t)q * len + run[q];
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if ((b[j][q] >> lane) & 1ull)
+                    pexp[dst + s_cnt[q][j * WAVES + wave] + (uint32_t)__popcll(b[j][q] & lt_mask)] = v[j] & ((1u << COARSE_ID_BITS) - 1u);
+            run[q] += s_tot[q];
+        }
+        __syncthreads();
+    }
+    if (tid < 4 && ((okmask >> tid) & 1u)) {
+        const uint32_t o = out0 + (uint32_t)tid * len;
+        ranges[(2 * cy + (tid >> 1)) * tiles_x + 2 * cx + (tid & 1)] = make_uint2(o, o + run[tid]);
+    }
+    if (tid == 0) atomicAdd(&ctrl->n_pairs, run[0] + run[1] + run[2] + run[3]);
+}
+
 static int ceil_log2(int v)
 {
     int bits = 0;
@@ -281,62 +389,73 @@ static int ceil_log2(int v)
     return bits;
 }
 
+// Coarse binning when the packed rect exists (frames up to 4096 px) and the expanded lists stay indexable in 32 bits.
+// GSR_FINE_BINNING=1 forces the fine path (A/B timing, and the test that both build the same frame).
 TileKeying tile_keying(const Workspace &ws)
 {
     TileKeying k;
-    k.bits_x = std::max(1, ceil_log2(ws.tiles_x));
-    k.bits_y = std::max(1, ceil_log2(ws.tiles_y + 1));  // one spare row value marks culled pairs
-    k.drop_from = (uint32_t)ws.tiles_y << k.bits_x;
+    k.coarse = rect_fits_8bit(ws) && ws.max_pairs <= (int64_t)0x3FFFFFFF && ws.n <= ((int64_t)1 << COARSE_ID_BITS);
+    if (k.coarse) {
+        const char *e = std::getenv("GSR_FINE_BINNING");
+        if (e && e[0] == '1') k.coarse = false;
+    }
+    k.grid_x = k.coarse ? ws.ctiles_x : ws.tiles_x;
+    k.grid_y = k.coarse ? ws.ctiles_y : ws.tiles_y;
+    k.bits_x = std::max(1, ceil_log2(k.grid_x));
+    k.bits_y = std::max(1, ceil_log2(k.grid_y + 1));  // one spare row value marks culled pairs
+    k.drop_from = (uint32_t)k.grid_y << k.bits_x;
     return k;
 }
 
-// Pairs of the depth-sorted gaussians, sorted by tile.  *pair_buf: which of pkey[]/pval[] holds the result.
-int pair_result_buf(const Workspace &ws)
+const uint32_t *tile_lists(const Workspace &ws)
 {
-    if (ws.n <= 0 || ws.max_pairs <= 0) return 0;
     const TileKeying tk = tile_keying(ws);
-    return ((tk.bits_x + tk.bits_y + 7) / 8) & 1;  // ping-pong parity of the tile sort's passes
+    if (tk.coarse) return ws.pexp;
+    if (ws.n <= 0 || ws.max_pairs <= 0) return ws.pval[0];
+    return ws.pval[((tk.bits_x + tk.bits_y + 7) / 8) & 1];  // ping-pong parity of the tile sort's passes
 }
 
-int launch_binning(const GsrOptions &opts, const Workspace &ws, int *pair_buf, hipStream_t s)
+int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s)
 {
-    *pair_buf = 0;
-    if (ws.n <= 0) return GSR_OK;
+    const int n_tiles = ws.tiles_x * ws.tiles_y;
+    if (ws.n <= 0) {  // no count kernel to clear the ranges
+        GSR_HIP(hipMemsetAsync(ws.ranges, 0, sizeof(uint2) * (size_t)n_tiles, s));
+        return GSR_OK;
+    }
     const bool packed_rect = rect_fits_8bit(ws);
     const Shard sh = {opts.tile_row_begin, opts.tile_row_step < 1 ? 1 : opts.tile_row_step};
-    const int n_tiles = ws.tiles_x * ws.tiles_y;
+    const Shard all = {0, 1};
     const TileKeying tk = tile_keying(ws);
+    const int n_ctiles = ws.ctiles_x * ws.ctiles_y;
     const uint32_t cap = (uint32_t)ws.max_pairs;
     const uint32_t limit = opts.draw_limit > 0 ? (uint32_t)opts.draw_limit : 0xFFFFFFFFu;
     // the count kernel also zeroes ranges[]: make sure its grid covers them
     const int nblk = (int)((std::max<int64_t>(ws.n, n_tiles) + EMIT_THREADS - 1) / EMIT_THREADS);
     const int nblk_n = (int)((ws.n + EMIT_THREADS - 1) / EMIT_THREADS);
-#define GSR_COUNT(P) hipLaunchKernelGGL(pair_count_kernel<P>, dim3(nblk), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
-                                        ws.ctrl, ws.rect, sh, ws.blk_sum, ws.ranges, n_tiles, limit)
-#define GSR_EMIT(P) hipLaunchKernelGGL(pair_emit_kernel<P>, dim3(nblk_n), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
-                                       ws.ctrl, ws.rect, sh, tk.bits_x, ws.tiles_y, ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0], limit)
-    if (packed_rect) GSR_COUNT(true); else GSR_COUNT(false);
+    // coarse: the cells are not sharded (a rank's tile rows r, r + G, ... touch every G/2-th cell row at best, and preprocess
+    // has already dropped the gaussians that reach none of its rows); the expansion keeps only this rank's tiles
+#define GSR_COUNT(P, C) hipLaunchKernelGGL((pair_count_kernel<P, C>), dim3(nblk), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
+                                           ws.ctrl, ws.rect, C ? all : sh, ws.blk_sum, ws.ranges, n_tiles, limit, ws.cranges, n_ctiles, ws.ctrl)
+#define GSR_EMIT(P, C) hipLaunchKernelGGL((pair_emit_kernel<P, C>), dim3(nblk_n), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
+                                          ws.ctrl, ws.rect, C ? all : sh, tk.bits_x, tk.grid_y, ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0], limit)
+    if (tk.coarse) GSR_COUNT(true, true); else if (packed_rect) GSR_COUNT(true, false); else GSR_COUNT(false, false);
     hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, ws.blk_sum, nblk_n, ws.ctrl, cap);
-    if (packed_rect) GSR_EMIT(true); else GSR_EMIT(false);
+    if (tk.coarse) GSR_EMIT(true, true); else if (packed_rect) GSR_EMIT(true, false); else GSR_EMIT(false, false);
 #undef GSR_COUNT
 #undef GSR_EMIT
     GSR_HIP(hipGetLastError());
-    // tile lists: stable sort by tile key; the first pass drops the pairs the emit kernel culled and leaves E in ctrl
-    return launch_pair_sort(ws, 0, &ws.ctrl->n_slots, 0, tk.bits_x + tk.bits_y, tk.drop_from, &ws.ctrl->n_pairs, pair_buf, s);
-}
-
-int launch_tile_ranges(const Workspace &ws, int pair_buf, hipStream_t s)
-{
-    const int n_tiles = ws.tiles_x * ws.tiles_y;
-    if (ws.n <= 0) {  // no count kernel ran: clear the ranges here
-        GSR_HIP(hipMemsetAsync(ws.ranges, 0, sizeof(uint2) * (size_t)n_tiles, s));
-        return GSR_OK;
-    }
     if (ws.max_pairs <= 0) return GSR_OK;
-    const TileKeying tk = tile_keying(ws);
+    // stable sort by cell / tile key; the first pass drops the pairs the emit kernel culled and leaves their count in ctrl
+    int pbuf = 0;
+    uint32_t *n_sorted = tk.coarse ? &ws.ctrl->n_cpairs : &ws.ctrl->n_pairs;
+    const int rc = launch_pair_sort(ws, 0, &ws.ctrl->n_slots, 0, tk.bits_x + tk.bits_y, tk.drop_from, n_sorted, &pbuf, s);
+    if (rc) return rc;
     const int grid = (int)std::min<int64_t>((ws.max_pairs + 1023) / 1024, 8192);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(grid), dim3(256), 0, s, ws.pkey[pair_buf], ws.ctrl, ws.ranges, tk.bits_x, ws.tiles_x,
-                       n_tiles, (uint32_t)grid * 256u);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(grid), dim3(256), 0, s, ws.pkey[pbuf], n_sorted, tk.coarse ? ws.cranges : ws.ranges, tk.bits_x,
+                       tk.grid_x, tk.grid_x * tk.grid_y, (uint32_t)grid * 256u);
+    if (tk.coarse)
+        hipLaunchKernelGGL(pair_expand_kernel, dim3(n_ctiles), dim3(EXPAND_THREADS), 0, s, ws.cranges, ws.pval[pbuf], sh, ws.ctiles_x,
+                           ws.tiles_x, ws.tiles_y, ws.pexp, ws.ranges, ws.ctrl);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

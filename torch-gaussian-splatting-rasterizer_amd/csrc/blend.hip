@@ -400,12 +400,12 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
     }
 }
 
-int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int pair_buf, void *out_image,
+int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, const uint32_t *lists, void *out_image,
                  float *out_T, hipStream_t s)
 {
     BlendArgs a;
     a.ranges = ws.ranges;
-    a.pval = ws.pval[pair_buf];
+    a.pval = lists;
     a.rec = ws.rec;
     a.out = out_image;
     a.out_T = out_T;

@@ -27,7 +27,7 @@ struct FrameCtrl {
     uint32_t sort_passes;    // depth-sort plan of this frame (sort.hip): passes that run (1..4) — the sorted ids end up in
     uint32_t sort_key_bits;  //   val[sort_passes & 1]; significant bits of key - bits(0.2f); digit width of the passes
     uint32_t sort_bits_rest; //   after the first.  Written by the pass-0 rowscan.
-    uint32_t _pad0;
+    uint32_t n_cpairs;       // coarse binning: 32x32-cell pairs that survive the sort's drop (count of the coarse ranges pass)
     // ---- everything below survives the per-frame clear ----
     uint32_t batch_overflow; // sticky across the views of gsr_render_batch
     uint32_t batch_need;     // largest D seen in the batch
@@ -66,12 +66,15 @@ struct Workspace {
     uint32_t *pkey[2];    // [max_pairs] tile ids
     uint32_t *pval[2];    // [max_pairs] gaussian ids
     uint2 *ranges;        // [tiles]
+    uint2 *cranges;       // [ctiles]  coarse binning: [begin, end) of every 32x32 cell's list in the sorted pair array
+    uint32_t *pexp;       // [4 * max_pairs]  coarse binning: the per-tile lists, expanded from the cell lists
     int *tile_order;      // [8 * ceil(tiles_y/8) * tiles_x] blend launch order
     uint32_t *blend_stats; // [tile_order slots][BLEND_STAT_WORDS] per-workgroup counters: plain stores, no atomics (40 k
                           // same-address atomics per frame put a 0.45 ms floor under the blend kernel)
     int64_t n;
     int64_t max_pairs;
     int tiles_x, tiles_y;
+    int ctiles_x, ctiles_y;  // 32x32 cells = 2x2 tiles
     int hist_blocks;      // row stride of `hist`
     size_t bytes;
 };
@@ -109,15 +112,18 @@ int launch_pair_sort(const Workspace &ws, int in_buf, const uint32_t *n_dev, int
                      uint32_t *n_out, int *result_buf, hipStream_t s);
 // Pair keys: (tile row << bits_x) | tile column; culled pairs carry the row `tiles_y` and are dropped from drop_from on.
 struct TileKeying {
-    int bits_x, bits_y;
+    int bits_x, bits_y;   // of the grid the pairs are generated on: tiles, or 32x32 cells when `coarse`
     uint32_t drop_from;
+    bool coarse;          // pairs are generated and sorted per 32x32 cell, then expanded into the tile lists (binning.hip)
+    int grid_x, grid_y;
 };
 TileKeying tile_keying(const Workspace &ws);
 inline bool rect_fits_8bit(const Workspace &ws) { return ws.tiles_x <= 256 && ws.tiles_y <= 256; }
-int launch_binning(const GsrOptions &opts, const Workspace &ws, int *pair_buf, hipStream_t s);
-int pair_result_buf(const Workspace &ws);  // which pair buffer launch_binning leaves the tile-sorted pairs in
-int launch_tile_ranges(const Workspace &ws, int pair_buf, hipStream_t s);
-int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, int pair_buf, void *out_image,
+// Stage 2b: pairs of the depth-sorted gaussians -> per-tile depth-ordered lists + ranges[] (count, scan, emit, sort, ranges,
+// and with coarse binning the expansion).
+int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s);
+const uint32_t *tile_lists(const Workspace &ws);  // the array ranges[] indexes after launch_binning (gaussian ids)
+int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, const uint32_t *lists, void *out_image,
                  float *out_T, hipStream_t s);
 int launch_blend_stats(FrameCtrl *ctrl, size_t workspace_bytes, hipStream_t s);
 
