@@ -28,7 +28,7 @@ def main():
 
     args = argparse.Namespace(workload=a.workload, gaussians=a.gaussians, camera=0, camera_set="one",
                               input_dir=None, trained_model_path=None)
-    cols, cam_list, n, W, H, _ = bench.build_workload(args)
+    cols, cam_list, n, W, H, _ = bench.build_workload(args.workload, args, getattr(args, "gaussians", 0))
     dev = torch.device("cuda:0")
     scene = renderer.GaussianScene.from_columns(cols, device=dev)
     cam = renderer.make_camera(*cam_list[0])

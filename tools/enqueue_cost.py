@@ -16,7 +16,7 @@ def main():
     from gsr_amd import renderer
 
     args = argparse.Namespace(workload="garden", gaussians=0, camera=0, camera_set="one", input_dir=None, trained_model_path=None)
-    cols, cam_list, n, W, H, _ = bench.build_workload(args)
+    cols, cam_list, n, W, H, _ = bench.build_workload(args.workload, args, getattr(args, "gaussians", 0))
     scene = renderer.GaussianScene.from_columns(cols, device=torch.device("cuda:0"))
     cam = renderer.make_camera(*cam_list[0])
     R = renderer.Rasterizer(scene)

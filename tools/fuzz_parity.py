@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-n", type=int, default=60000)
     ap.add_argument("--case-seed", type=int, default=None, help="replay one case (printed by a failure) with diagnostics")
+    ap.add_argument("--report-flips", action="store_true", help="print every case in which a pixel sits on the alpha > 1/255 step "
+                    "(differs from the oracle by more than 1e-5): how often, and by how much, the tolerance is actually used")
     a = ap.parse_args()
 
     import gsr_amd  # noqa: F401
@@ -87,6 +89,11 @@ def main():
                 print(f"pixels off by > 1e-5: {(d > 1e-5).sum()} of {d.size}; > 4.5e-3: {(d > 4.5e-3).sum()}; worst colour {d.max():.6f}, worst T {dT.max():.6f}")
                 for y, x in zip(*np.unravel_index(np.argsort(-d, axis=None)[:6], d.shape)):
                     print(f"   pixel ({x},{y}) colour diff {d[y, x]:.6f}  T diff {dT[y, x]:.6f}  T oracle {oT[y, x]:.6f}")
+            if a.report_flips:
+                dpx = np.abs(img.cpu().numpy().astype(np.float64) - oimg).max(2)
+                if (dpx > 1e-5).any():
+                    print(f"flip: {desc}: {(dpx > 1e-5).sum()} of {dpx.size} pixels off by > 1e-5, worst {dpx.max():.2e} "
+                          f"(one step = MIN_ALPHA * T * c <= 3.9e-3); share of samples {(np.abs(img.cpu().numpy() - oimg) > 1e-5).mean():.2e}", flush=True)
             close(img.cpu().numpy(), oimg)
             close(T.cpu().numpy()[..., None], oT[..., None])
             assert torch.equal(R.render(cam), img), "not reproducible"

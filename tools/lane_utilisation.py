@@ -32,7 +32,7 @@ def main():
 
     args = argparse.Namespace(workload=a.workload, gaussians=a.gaussians, camera=a.camera, camera_set="one",
                               input_dir=None, trained_model_path=None)
-    cols, cam_list, n, W, H, _ = bench.build_workload(args)
+    cols, cam_list, n, W, H, _ = bench.build_workload(args.workload, args, getattr(args, "gaussians", 0))
     packed = utils.pack_gaussians(cols)
     cam = cpu_oracle.camera(*cam_list[0])
     pre = cpu_oracle.preprocess(packed, cam)

@@ -424,7 +424,10 @@ int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s)
     }
     const bool packed_rect = rect_fits_8bit(ws);
     const Shard sh = {opts.tile_row_begin, opts.tile_row_step < 1 ? 1 : opts.tile_row_step};
-    const Shard all = {0, 1};
+    // cells of a shard: with an even row step the rank's tile rows begin + k step fall into the cell rows (begin >> 1) + k (step >> 1),
+    // each holding exactly one of them; with an odd step (or none) every cell row can hold one.  The expansion keeps only this
+    // rank's tiles either way.
+    const Shard csh = (sh.step > 1 && sh.step % 2 == 0) ? Shard{sh.begin >> 1, sh.step >> 1} : Shard{0, 1};
     const TileKeying tk = tile_keying(ws);
     const int n_ctiles = ws.ctiles_x * ws.ctiles_y;
     const uint32_t cap = (uint32_t)ws.max_pairs;
@@ -432,12 +435,10 @@ int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s)
     // the count kernel also zeroes ranges[]: make sure its grid covers them
     const int nblk = (int)((std::max<int64_t>(ws.n, n_tiles) + EMIT_THREADS - 1) / EMIT_THREADS);
     const int nblk_n = (int)((ws.n + EMIT_THREADS - 1) / EMIT_THREADS);
-    // coarse: the cells are not sharded (a rank's tile rows r, r + G, ... touch every G/2-th cell row at best, and preprocess
-    // has already dropped the gaussians that reach none of its rows); the expansion keeps only this rank's tiles
 #define GSR_COUNT(P, C) hipLaunchKernelGGL((pair_count_kernel<P, C>), dim3(nblk), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
-                                           ws.ctrl, ws.rect, C ? all : sh, ws.blk_sum, ws.ranges, n_tiles, limit, ws.cranges, n_ctiles, ws.ctrl)
+                                           ws.ctrl, ws.rect, C ? csh : sh, ws.blk_sum, ws.ranges, n_tiles, limit, ws.cranges, n_ctiles, ws.ctrl)
 #define GSR_EMIT(P, C) hipLaunchKernelGGL((pair_emit_kernel<P, C>), dim3(nblk_n), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
-                                          ws.ctrl, ws.rect, C ? all : sh, tk.bits_x, tk.grid_y, ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0], limit)
+                                          ws.ctrl, ws.rect, C ? csh : sh, tk.bits_x, tk.grid_y, ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0], limit)
     if (tk.coarse) GSR_COUNT(true, true); else if (packed_rect) GSR_COUNT(true, false); else GSR_COUNT(false, false);
     hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, ws.blk_sum, nblk_n, ws.ctrl, cap);
     if (tk.coarse) GSR_EMIT(true, true); else if (packed_rect) GSR_EMIT(true, false); else GSR_EMIT(false, false);
