@@ -138,7 +138,8 @@ int gsr_camera_setup(const double qvec[4], const double tvec[3], double fx_full,
                      int64_t cam_height, int32_t width, int32_t height, GsrCamera *out /* [host] */);
 
 /* Bytes of scratch one frame needs for n gaussians, a width x height target and room for max_pairs
- * (gaussian,tile) pairs.  max_pairs is the caller's bound on D; exceeding it is reported, never UB. */
+ * pairs.  max_pairs is the caller's bound on D = the (gaussian, 32x32 cell) pairs of a frame (frames wider than 4096 px:
+ * (gaussian, 16x16 tile) pairs); GsrStats.n_pairs_bbox reports what a frame needed; exceeding it is reported, never UB. */
 int gsr_workspace_bytes(int64_t n, int32_t width, int32_t height, int64_t max_pairs, size_t *bytes /* [host] */);
 
 /* Stage 1 — per-gaussian preprocessing, fused: rasterize.py:354-420 (means, cov3D, opacity, SH colour,
