@@ -264,7 +264,7 @@ def main():
                        "sharding": f"tile rows interleaved over {world} GPU(s), RCCL gather to rank 0" if world > 1 else "none",
                        "reference_compat": True, "early_out_T": args.early_out_T, "sh_storage": "f16" if args.sh_half else "f32",
                        "frame_storage": "bf16 (fp32 accumulation)" if args.bf16_output else "f32",
-                       "blend_impl": {0: "valu", 1: "valu, plain-C walk", 2: "mfma (experimental)"}[args.blend_impl]},
+                       "blend_impl": {0: "valu", 1: "valu, plain-C walk", 2: "mfma (experimental)"}.get(args.blend_impl, str(args.blend_impl))},
             "stats_rank0_shard": shard_stats,
         }
 

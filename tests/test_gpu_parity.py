@@ -385,7 +385,7 @@ def test_blend_counters_describe_the_last_blend(G):
     R.render(cam)
     assert R.last_stats == first and first["wave_entries"] > 0
     R.render(cam, G.renderer.make_options(blend_impl=2))
-    assert R.last_stats["fetched_entries"] == first["fetched_entries"]
+    assert first["fetched_entries"] <= R.last_stats["fetched_entries"] <= 1.05 * first["fetched_entries"]   # batches of 256 vs 128
     assert abs(R.last_stats["wave_entries"] - first["wave_entries"]) <= 0.05 * first["wave_entries"]
     # stages 1 and 2 only: the frame reset cleared the totals and no blend has refilled them
     ws = R._workspace(cam.width, cam.height)
@@ -537,9 +537,10 @@ def test_depth_sort_plans_its_passes_from_the_key_range(G):
 
 
 def test_hand_scheduled_blend_walk_equals_the_plain_kernel(G):
-    """blend.hip: the default kernel walks its survivors in one hand-written asm statement (EXEC-masked update, rolling LDS
-    prefetch); blend_impl = 1 is the same kernel with that walk in plain C.  Same instructions on the data path, so frames,
-    transmittance and counters must be identical bit for bit — whole frames, shards, early-out, bf16 store, non-compat, the
+    """blend.hip: the default kernel (two quadrants per wave) walks its survivors in one hand-written asm statement
+    (EXEC-masked update, unguarded fast path, shared terms of the quadratic, rolling LDS prefetch); blend_impl = 1 is the
+    plain-C kernel (one quadrant per wave).  Same operations on the same values, so frames, transmittance and the evaluated
+    counts must be identical bit for bit — whole frames, shards, early-out, bf16 store, non-compat, the
     fixtures with their edge cases (a frame-covering gaussian, the 0.99 cap, frames not a multiple of 16)."""
     mk = G.renderer.make_options
     cases = [_medium(G)[:2], _medium(G, n=300_000, shift=1.6, pose=7)[:2]]
@@ -554,7 +555,10 @@ def test_hand_scheduled_blend_walk_equals_the_plain_kernel(G):
             sa = dict(R.last_stats)
             b, Tb = R.render(cam, mk(blend_impl=1, **kw), return_T=True)
             assert torch.equal(a, b) and torch.equal(Ta, Tb), kw
-            assert sa == R.last_stats, kw
+            sb = R.last_stats
+            # same lists, same evaluations; the product kernel stages 128 entries per batch, the plain one 256, so a tile that
+            # saturates stops fetching a little earlier in the former
+            assert all(sa[k] == sb[k] for k in sa if k != "fetched_entries") and sa["fetched_entries"] <= sb["fetched_entries"], kw
 
 
 @pytest.mark.parametrize("name,prefix", [("medium", ""), ("f3_edge.npz", "a_"), ("f3_edge.npz", "b_")])

@@ -2,22 +2,23 @@
 //
 // Replaces the reference's hot loop: the driver at rasterize.py:436-446 and rasterize_gaussian
 // (:255-305), which together visit ONE gaussian at a time from the Python interpreter.  Here one
-// 256-thread workgroup owns one tile; wave w owns the 8x8 quadrant (w&1, w>>1) and one lane one pixel.
+// workgroup owns one tile, a wave one or two of its 8x8 quadrants, a lane one pixel of each.
 //
 // Per tile list (depth-ordered by the two radix sorts):
-//   - 256 entries at a time are staged in LDS: each thread gathers one 48-B record (3 x 16-B loads)
-//     addressed by the pair value, so HBM/L2 sees 16-B vector loads and the list itself is read coalesced;
-//   - footprint_hits_rect (footprint.h) decides, 64 entries per instruction, whether an entry can touch this
-//     wave's quadrant; the wave walks only the surviving bits of the ballot (scalar loop, no divergence),
-//     two survivors per trip so the second one's LDS broadcast reads overlap the first one's arithmetic;
+//   - 128 (256) entries at a time are staged in LDS: each thread gathers one 48-B record (3 x 16-B loads)
+//     addressed by the list entry, so HBM/L2 sees 16-B vector loads and the list itself is read coalesced;
+//   - footprint.h decides, 64 entries per instruction, whether an entry can touch the wave's quadrant(s); the wave
+//     walks only the surviving bits of the ballot (scalar loop, no divergence);
 //   - per pixel the reference's arithmetic: power (log2 domain, coefficients pre-scaled in preprocess),
 //     alpha = min(opacity * 2^power, 0.99), contribute iff alpha > 1/255 and power <= 0 (:285-291),
 //     C += alpha * T * rgb, T *= 1 - alpha (:295-303);
-//   - saturation early-out by wave ballot: a wave stops once T <= opts.early_out_T holds for all its 64 pixels,
-//     the workgroup stops fetching once all four waves have.  The default threshold 0 is EXACT, not an
+//   - saturation early-out by wave ballot: a quadrant stops once T <= opts.early_out_T holds for all its 64 pixels,
+//     the workgroup stops fetching once every wave has.  The default threshold 0 is EXACT, not an
 //     approximation of the reference's "blend every gaussian" (Q5): transmittance only ever shrinks, and once it
 //     has underflowed to 0.0f (a few dozen near-opaque layers) alpha*T*rgb = 0 and T stays 0 — the remaining
 //     entries cannot change a bit.  early_out_T > 0 (INRIA uses 1e-4) is the usual bounded approximation.
+// Two kernels share this: blend_kernel, the plain-C statement (blend_impl = 1), and blend_half_kernel, the product, whose
+// inner walk is one hand-scheduled asm statement — bit-identical frames (its comment has the measurements).
 //
 // Launch order: list lengths are heavy-tailed (longest ~3.5x the mean) and a frame is only ~4 rounds of
 // resident workgroups, so tiles are launched longest-first (tile_order_kernel: per XCD group, bucketed by
@@ -25,9 +26,9 @@
 // most of their gaussians, hit the same L2, and heavy image regions are spread over all XCDs.
 //
 // Roofline: algorithmic bytes = 40 per consumed entry (4 id + 36 record) + 12 per pixel
-// + 8 per tile range.  The kernel is bound on-chip, not by HBM: ~21 VALU issues per evaluated (quadrant, entry) and three
-// wave-wide LDS broadcast reads of its record (10 LDS cycles; the CU's one LDS pipe is 72 % busy).  Removing VALU work
-// alone does not move it (DESIGN.md §5 lists the variants); bench.py reports the HBM fraction and the VALU issue fraction.
+// + 8 per tile range.  The kernel is bound on-chip, not by HBM: per evaluated (quadrant, entry) ~15 VALU issues incl. one
+// quarter-rate v_exp_f32, and the record's three wave-wide LDS broadcast reads (10 LDS cycles).  bench.py reports the HBM
+// fraction (the contract figure) and, from the committed PMC passes, the VALU issue and LDS busy fractions.
 #include "gsr_internal.h"
 #include "blend_args.h"
 #include "footprint.h"
@@ -55,34 +56,40 @@ __device__ __forceinline__ void blend_one(const float2 g, const float4 c, const 
     T = T - w;
 }
 
-// The survivor walk of one 64-entry chunk as ONE asm statement (m != 0 on entry): for every set bit of the ballot `m`, in
-// order, read the record from LDS (wave-uniform address: three broadcast reads) and blend it into the lane's pixel — the
-// arithmetic of blend_one above, instruction for instruction as the compiler emits it (w = T alpha, T = fma(-T, alpha, T)),
-// so frames are bit-identical to the plain kernel (blend_impl = 1; tools/blend_ab.py checks it).  What differs:
+// The survivor walk of one 64-entry chunk as ONE asm statement (m != 0 on entry), for a wave that owns TWO 8x8 quadrants side
+// by side (a 16x8 half-tile), a lane one pixel in each: for every set bit of `m`, in order, read the record from LDS
+// (wave-uniform address: three broadcast reads, once for both quadrants) and blend it into the lane's pixel of quadrant A if
+// bit `ma` is set, of quadrant B if `mb` is — the arithmetic of blend_one above, instruction for instruction as the compiler
+// emits it (w = T alpha, T = fma(-T, alpha, T)), with dy, C dy and t1 = fma(C dy, dy, L) computed once per record: the same
+// operations on the same values as two separate evaluations, so frames are bit-identical to the plain kernel (blend_impl = 1;
+// tests + tools/blend_ab.py check it).  What differs from what the compiler makes of the plain loop:
 //   - the validity test goes straight into EXEC: two v_cmpx, the five update instructions run under it, one s_mov restores
 //     EXEC.  tools/valu_microbench.hip: v_cmp to an SGPR pair 1.76 ns and the v_cndmask that consumes it 1.83 ns per
 //     wave-instruction per SIMD, v_cmpx 1.1 ns like any plain VALU.  Lanes that fail keep C and T untouched, which is what
 //     adding w = 0 did.
-//   - v_cmpx_le sits between v_exp_f32 and the v_min_f32 that consumes it: on gfx940+ a VALU reading a transcendental's result
+//   - v_cmpx_le (or an s_nop) sits between v_exp_f32 and its consumer: on gfx940+ a VALU reading a transcendental's result
 //     needs one wait state; the compiler inserts it for its own code, never inside inline asm (without it the first four lanes
 //     of every eight read a stale value — found by tools/cmpx_test.hip).
-//   - the walk itself costs 5 scalar instructions per survivor (s_ff1 + s_bitset0 pop, loop test, EXEC restore) instead of the
-//     compiler's 10.8 (64-bit m & (m - 1) as add/addc/and, address shifts, selects), and the accumulators never change
-//     registers (the compiler's one-or-two-per-trip loop copied T and the colour sums on every trip: 2 VALU per entry).
-//   - survivors flagged `fast` by the culling lane (footprint_classify: neither the 0.99 clamp nor the `p <= L` test can fire
-//     anywhere on this wave's quadrant) take an evaluation without v_min and the second v_cmpx: 15 instead of 17 VALU;
-//   - records roll through two register sets: while survivor k is evaluated the reads of survivor k+1 are in flight (counted
+//   - records flagged `fa` / `fb` by the culling lane (footprint_classify: neither the 0.99 clamp nor the `p <= L` test can
+//     fire anywhere on that quadrant) take an evaluation without v_min and the second v_cmpx;
+//   - the walk itself costs ~6 scalar instructions per record (s_ff1 + s_bitset0 pop, bit tests, EXEC restore) instead of the
+//     compiler's 10.8 per evaluation, and the accumulators never change registers (the compiler's loop copied them every trip);
+//   - records roll through two register sets: while record k is evaluated the reads of record k+1 are in flight (counted
 //     waits: LDS returns in order; the lgkmcnt(0) up front retires anything older, scalar loads included, which do not).
-// Registers v40-v63 are named explicitly (an asm statement takes at most 30 operands): v40/v41 addresses then temporaries,
-// v42-v51 and v52-v61 the two records, v62/v63 temporaries; the kernel stays at 64 VGPRs = 8 waves per SIMD.
-// Measured on the garden frame (tools/blend_ab.py, interleaved A/B in one process): 0.606 ms against 0.722 ms for the plain
-// kernel (0.642 ms with every survivor on the guarded path).  Variants that did not pay: two quadrants per
-// wave (16x8 half-tiles, one LDS read for both: +4 %, the LDS pipe is not the limit); skipping the pass of an empty 32-lane
-// EXEC half (the hardware does not: 8x4 culling is pointless); the same walk without the rolling prefetch (equal: 8 waves per
-// SIMD already hide the LDS latency).  The text below is generated by tools/gen_blend_walk.py.
-// lds_chunk = LDS byte address of the chunk's first record (plane 0), identical in every lane.
-__device__ __forceinline__ void blend_walk_asm(unsigned long long m, unsigned long long fast, unsigned lds_chunk, float fpx, float fpy,
-                                               float &T, float &Cr, float &Cg, float &Cb)
+// Registers v39-v63 are named explicitly (an asm statement takes at most 30 operands): v40/v41 addresses then temporaries,
+// v42-v51 and v52-v61 the two records, v39/v62/v63 temporaries; the kernel stays at 64 VGPRs = 8 waves per SIMD.
+// Measured on the bicycle frame (tools/blend_ab.py, interleaved A/B in one process): plain kernel 0.738 ms; EXEC-masked
+// update + hand-written walk, one quadrant per wave 0.66 ms; + unguarded fast path 0.613 ms; two quadrants per wave (this)
+// 0.570 ms.  PMC per launch, plain (round 1) -> one quadrant -> this: VALU 549 M -> 441 M -> 402 M wave-instructions,
+// LDS-array cycles 267 M -> 277 M -> 177 M (82 % -> 52 % of the kernel's cycles), SALU 236 M -> 172 M -> 173 M.
+// Did not pay: skipping the pass of an empty 32-lane EXEC half (the hardware does not: 8x4 culling is pointless); the walk
+// without the rolling prefetch (equal: 8 waves per SIMD already hide the LDS latency); two quadrants per wave with the
+// COMPILER's walk (+4 %: its register copies and selects ate the saved reads).
+// The text below is generated by tools/gen_blend_walk.py.  lds_chunk = LDS byte address of the chunk's first record
+// (plane 0; the planes are 2048 B apart), identical in every lane.
+__device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned long long ma, unsigned long long mb, unsigned long long fa,
+                                                unsigned long long fb, unsigned lds_chunk, float fpxa, float fpxb, float fpy, float &Ta,
+                                                float &Cra, float &Cga, float &Cba, float &Tb, float &Crb, float &Cgb, float &Cbb)
 {
     int ia, ib;
     asm volatile(
@@ -91,8 +98,8 @@ __device__ __forceinline__ void blend_walk_asm(unsigned long long m, unsigned lo
         "s_bitset0_b64 %[m], %[ia]\n\t"
         "v_lshl_add_u32 v40, %[ia], 4, %[base]\n\t"
         "ds_read_b64 v[42:43], v40\n\t"
-        "ds_read_b128 v[44:47], v40 offset:4096\n\t"
-        "ds_read_b128 v[48:51], v40 offset:8192\n\t"
+        "ds_read_b128 v[44:47], v40 offset:2048\n\t"
+        "ds_read_b128 v[48:51], v40 offset:4096\n\t"
         "1:\n\t"
         "s_cmp_eq_u64 %[m], 0\n\t"
         "s_cbranch_scc1 3f\n\t"
@@ -100,149 +107,282 @@ __device__ __forceinline__ void blend_walk_asm(unsigned long long m, unsigned lo
         "s_bitset0_b64 %[m], %[ib]\n\t"
         "v_lshl_add_u32 v41, %[ib], 4, %[base]\n\t"
         "ds_read_b64 v[52:53], v41\n\t"
-        "ds_read_b128 v[54:57], v41 offset:4096\n\t"
-        "ds_read_b128 v[58:61], v41 offset:8192\n\t"
+        "ds_read_b128 v[54:57], v41 offset:2048\n\t"
+        "ds_read_b128 v[58:61], v41 offset:4096\n\t"
         "s_waitcnt lgkmcnt(3)\n\t"
-        "v_sub_f32 v40, v42, %[fpx]\n\t"
         "v_sub_f32 v41, v43, %[fpy]\n\t"
+        "v_mul_f32 v39, v46, v41\n\t"
+        "v_fma_f32 v39, v39, v41, v48\n\t"
+        "s_bitcmp1_b64 %[ma], %[ia]\n\t"
+        "s_cbranch_scc0 10f\n\t"
+        "v_sub_f32 v40, v42, %[fpxa]\n\t"
         "v_mul_f32 v62, v44, v40\n\t"
         "v_fma_f32 v62, v45, v41, v62\n\t"
-        "v_mul_f32 v63, v46, v41\n\t"
-        "v_fma_f32 v63, v63, v41, v48\n\t"
-        "v_fma_f32 v62, v40, v62, v63\n\t"
+        "v_fma_f32 v62, v40, v62, v39\n\t"
         "v_exp_f32 v63, v62\n\t"
-        "s_bitcmp1_b64 %[fast], %[ia]\n\t"
-        "s_cbranch_scc1 10f\n\t"
+        "s_bitcmp1_b64 %[fa], %[ia]\n\t"
+        "s_cbranch_scc1 11f\n\t"
         "v_cmpx_le_f32 vcc, v62, v48\n\t"
         "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
-        "v_mul_f32 v40, %[T], v63\n\t"
-        "v_fma_f32 %[Cr], v40, v49, %[Cr]\n\t"
-        "v_fma_f32 %[Cg], v40, v50, %[Cg]\n\t"
-        "v_fma_f32 %[Cb], v40, v51, %[Cb]\n\t"
-        "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
+        "v_mul_f32 v40, %[Ta], v63\n\t"
+        "v_fma_f32 %[Cra], v40, v49, %[Cra]\n\t"
+        "v_fma_f32 %[Cga], v40, v50, %[Cga]\n\t"
+        "v_fma_f32 %[Cba], v40, v51, %[Cba]\n\t"
+        "v_fma_f32 %[Ta], -%[Ta], v63, %[Ta]\n\t"
         "s_mov_b64 exec, -1\n\t"
-        "s_branch 11f\n\t"
-        "10:\n\t"
+        "s_branch 12f\n\t"
+        "11:\n\t"
         "s_nop 0\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
-        "v_mul_f32 v40, %[T], v63\n\t"
-        "v_fma_f32 %[Cr], v40, v49, %[Cr]\n\t"
-        "v_fma_f32 %[Cg], v40, v50, %[Cg]\n\t"
-        "v_fma_f32 %[Cb], v40, v51, %[Cb]\n\t"
-        "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
+        "v_mul_f32 v40, %[Ta], v63\n\t"
+        "v_fma_f32 %[Cra], v40, v49, %[Cra]\n\t"
+        "v_fma_f32 %[Cga], v40, v50, %[Cga]\n\t"
+        "v_fma_f32 %[Cba], v40, v51, %[Cba]\n\t"
+        "v_fma_f32 %[Ta], -%[Ta], v63, %[Ta]\n\t"
         "s_mov_b64 exec, -1\n\t"
-        "11:\n\t"
+        "12:\n\t"
+        "10:\n\t"
+        "s_bitcmp1_b64 %[mb], %[ia]\n\t"
+        "s_cbranch_scc0 13f\n\t"
+        "v_sub_f32 v40, v42, %[fpxb]\n\t"
+        "v_mul_f32 v62, v44, v40\n\t"
+        "v_fma_f32 v62, v45, v41, v62\n\t"
+        "v_fma_f32 v62, v40, v62, v39\n\t"
+        "v_exp_f32 v63, v62\n\t"
+        "s_bitcmp1_b64 %[fb], %[ia]\n\t"
+        "s_cbranch_scc1 14f\n\t"
+        "v_cmpx_le_f32 vcc, v62, v48\n\t"
+        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[Tb], v63\n\t"
+        "v_fma_f32 %[Crb], v40, v49, %[Crb]\n\t"
+        "v_fma_f32 %[Cgb], v40, v50, %[Cgb]\n\t"
+        "v_fma_f32 %[Cbb], v40, v51, %[Cbb]\n\t"
+        "v_fma_f32 %[Tb], -%[Tb], v63, %[Tb]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 15f\n\t"
+        "14:\n\t"
+        "s_nop 0\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[Tb], v63\n\t"
+        "v_fma_f32 %[Crb], v40, v49, %[Crb]\n\t"
+        "v_fma_f32 %[Cgb], v40, v50, %[Cgb]\n\t"
+        "v_fma_f32 %[Cbb], v40, v51, %[Cbb]\n\t"
+        "v_fma_f32 %[Tb], -%[Tb], v63, %[Tb]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "15:\n\t"
+        "13:\n\t"
         "s_cmp_eq_u64 %[m], 0\n\t"
         "s_cbranch_scc1 4f\n\t"
         "s_ff1_i32_b64 %[ia], %[m]\n\t"
         "s_bitset0_b64 %[m], %[ia]\n\t"
         "v_lshl_add_u32 v40, %[ia], 4, %[base]\n\t"
         "ds_read_b64 v[42:43], v40\n\t"
-        "ds_read_b128 v[44:47], v40 offset:4096\n\t"
-        "ds_read_b128 v[48:51], v40 offset:8192\n\t"
+        "ds_read_b128 v[44:47], v40 offset:2048\n\t"
+        "ds_read_b128 v[48:51], v40 offset:4096\n\t"
         "s_waitcnt lgkmcnt(3)\n\t"
-        "v_sub_f32 v40, v52, %[fpx]\n\t"
         "v_sub_f32 v41, v53, %[fpy]\n\t"
+        "v_mul_f32 v39, v56, v41\n\t"
+        "v_fma_f32 v39, v39, v41, v58\n\t"
+        "s_bitcmp1_b64 %[ma], %[ib]\n\t"
+        "s_cbranch_scc0 16f\n\t"
+        "v_sub_f32 v40, v52, %[fpxa]\n\t"
         "v_mul_f32 v62, v54, v40\n\t"
         "v_fma_f32 v62, v55, v41, v62\n\t"
-        "v_mul_f32 v63, v56, v41\n\t"
-        "v_fma_f32 v63, v63, v41, v58\n\t"
-        "v_fma_f32 v62, v40, v62, v63\n\t"
+        "v_fma_f32 v62, v40, v62, v39\n\t"
         "v_exp_f32 v63, v62\n\t"
-        "s_bitcmp1_b64 %[fast], %[ib]\n\t"
-        "s_cbranch_scc1 12f\n\t"
+        "s_bitcmp1_b64 %[fa], %[ib]\n\t"
+        "s_cbranch_scc1 17f\n\t"
         "v_cmpx_le_f32 vcc, v62, v58\n\t"
         "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
-        "v_mul_f32 v40, %[T], v63\n\t"
-        "v_fma_f32 %[Cr], v40, v59, %[Cr]\n\t"
-        "v_fma_f32 %[Cg], v40, v60, %[Cg]\n\t"
-        "v_fma_f32 %[Cb], v40, v61, %[Cb]\n\t"
-        "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
+        "v_mul_f32 v40, %[Ta], v63\n\t"
+        "v_fma_f32 %[Cra], v40, v59, %[Cra]\n\t"
+        "v_fma_f32 %[Cga], v40, v60, %[Cga]\n\t"
+        "v_fma_f32 %[Cba], v40, v61, %[Cba]\n\t"
+        "v_fma_f32 %[Ta], -%[Ta], v63, %[Ta]\n\t"
         "s_mov_b64 exec, -1\n\t"
-        "s_branch 13f\n\t"
-        "12:\n\t"
+        "s_branch 18f\n\t"
+        "17:\n\t"
         "s_nop 0\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
-        "v_mul_f32 v40, %[T], v63\n\t"
-        "v_fma_f32 %[Cr], v40, v59, %[Cr]\n\t"
-        "v_fma_f32 %[Cg], v40, v60, %[Cg]\n\t"
-        "v_fma_f32 %[Cb], v40, v61, %[Cb]\n\t"
-        "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
+        "v_mul_f32 v40, %[Ta], v63\n\t"
+        "v_fma_f32 %[Cra], v40, v59, %[Cra]\n\t"
+        "v_fma_f32 %[Cga], v40, v60, %[Cga]\n\t"
+        "v_fma_f32 %[Cba], v40, v61, %[Cba]\n\t"
+        "v_fma_f32 %[Ta], -%[Ta], v63, %[Ta]\n\t"
         "s_mov_b64 exec, -1\n\t"
-        "13:\n\t"
+        "18:\n\t"
+        "16:\n\t"
+        "s_bitcmp1_b64 %[mb], %[ib]\n\t"
+        "s_cbranch_scc0 19f\n\t"
+        "v_sub_f32 v40, v52, %[fpxb]\n\t"
+        "v_mul_f32 v62, v54, v40\n\t"
+        "v_fma_f32 v62, v55, v41, v62\n\t"
+        "v_fma_f32 v62, v40, v62, v39\n\t"
+        "v_exp_f32 v63, v62\n\t"
+        "s_bitcmp1_b64 %[fb], %[ib]\n\t"
+        "s_cbranch_scc1 20f\n\t"
+        "v_cmpx_le_f32 vcc, v62, v58\n\t"
+        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[Tb], v63\n\t"
+        "v_fma_f32 %[Crb], v40, v59, %[Crb]\n\t"
+        "v_fma_f32 %[Cgb], v40, v60, %[Cgb]\n\t"
+        "v_fma_f32 %[Cbb], v40, v61, %[Cbb]\n\t"
+        "v_fma_f32 %[Tb], -%[Tb], v63, %[Tb]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 21f\n\t"
+        "20:\n\t"
+        "s_nop 0\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[Tb], v63\n\t"
+        "v_fma_f32 %[Crb], v40, v59, %[Crb]\n\t"
+        "v_fma_f32 %[Cgb], v40, v60, %[Cgb]\n\t"
+        "v_fma_f32 %[Cbb], v40, v61, %[Cbb]\n\t"
+        "v_fma_f32 %[Tb], -%[Tb], v63, %[Tb]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "21:\n\t"
+        "19:\n\t"
         "s_branch 1b\n\t"
         "3:\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        "v_sub_f32 v40, v42, %[fpx]\n\t"
         "v_sub_f32 v41, v43, %[fpy]\n\t"
+        "v_mul_f32 v39, v46, v41\n\t"
+        "v_fma_f32 v39, v39, v41, v48\n\t"
+        "s_bitcmp1_b64 %[ma], %[ia]\n\t"
+        "s_cbranch_scc0 22f\n\t"
+        "v_sub_f32 v40, v42, %[fpxa]\n\t"
         "v_mul_f32 v62, v44, v40\n\t"
         "v_fma_f32 v62, v45, v41, v62\n\t"
-        "v_mul_f32 v63, v46, v41\n\t"
-        "v_fma_f32 v63, v63, v41, v48\n\t"
-        "v_fma_f32 v62, v40, v62, v63\n\t"
+        "v_fma_f32 v62, v40, v62, v39\n\t"
         "v_exp_f32 v63, v62\n\t"
-        "s_bitcmp1_b64 %[fast], %[ia]\n\t"
-        "s_cbranch_scc1 14f\n\t"
+        "s_bitcmp1_b64 %[fa], %[ia]\n\t"
+        "s_cbranch_scc1 23f\n\t"
         "v_cmpx_le_f32 vcc, v62, v48\n\t"
         "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
-        "v_mul_f32 v40, %[T], v63\n\t"
-        "v_fma_f32 %[Cr], v40, v49, %[Cr]\n\t"
-        "v_fma_f32 %[Cg], v40, v50, %[Cg]\n\t"
-        "v_fma_f32 %[Cb], v40, v51, %[Cb]\n\t"
-        "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
+        "v_mul_f32 v40, %[Ta], v63\n\t"
+        "v_fma_f32 %[Cra], v40, v49, %[Cra]\n\t"
+        "v_fma_f32 %[Cga], v40, v50, %[Cga]\n\t"
+        "v_fma_f32 %[Cba], v40, v51, %[Cba]\n\t"
+        "v_fma_f32 %[Ta], -%[Ta], v63, %[Ta]\n\t"
         "s_mov_b64 exec, -1\n\t"
-        "s_branch 15f\n\t"
-        "14:\n\t"
+        "s_branch 24f\n\t"
+        "23:\n\t"
         "s_nop 0\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
-        "v_mul_f32 v40, %[T], v63\n\t"
-        "v_fma_f32 %[Cr], v40, v49, %[Cr]\n\t"
-        "v_fma_f32 %[Cg], v40, v50, %[Cg]\n\t"
-        "v_fma_f32 %[Cb], v40, v51, %[Cb]\n\t"
-        "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
+        "v_mul_f32 v40, %[Ta], v63\n\t"
+        "v_fma_f32 %[Cra], v40, v49, %[Cra]\n\t"
+        "v_fma_f32 %[Cga], v40, v50, %[Cga]\n\t"
+        "v_fma_f32 %[Cba], v40, v51, %[Cba]\n\t"
+        "v_fma_f32 %[Ta], -%[Ta], v63, %[Ta]\n\t"
         "s_mov_b64 exec, -1\n\t"
-        "15:\n\t"
+        "24:\n\t"
+        "22:\n\t"
+        "s_bitcmp1_b64 %[mb], %[ia]\n\t"
+        "s_cbranch_scc0 25f\n\t"
+        "v_sub_f32 v40, v42, %[fpxb]\n\t"
+        "v_mul_f32 v62, v44, v40\n\t"
+        "v_fma_f32 v62, v45, v41, v62\n\t"
+        "v_fma_f32 v62, v40, v62, v39\n\t"
+        "v_exp_f32 v63, v62\n\t"
+        "s_bitcmp1_b64 %[fb], %[ia]\n\t"
+        "s_cbranch_scc1 26f\n\t"
+        "v_cmpx_le_f32 vcc, v62, v48\n\t"
+        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[Tb], v63\n\t"
+        "v_fma_f32 %[Crb], v40, v49, %[Crb]\n\t"
+        "v_fma_f32 %[Cgb], v40, v50, %[Cgb]\n\t"
+        "v_fma_f32 %[Cbb], v40, v51, %[Cbb]\n\t"
+        "v_fma_f32 %[Tb], -%[Tb], v63, %[Tb]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 27f\n\t"
+        "26:\n\t"
+        "s_nop 0\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[Tb], v63\n\t"
+        "v_fma_f32 %[Crb], v40, v49, %[Crb]\n\t"
+        "v_fma_f32 %[Cgb], v40, v50, %[Cgb]\n\t"
+        "v_fma_f32 %[Cbb], v40, v51, %[Cbb]\n\t"
+        "v_fma_f32 %[Tb], -%[Tb], v63, %[Tb]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "27:\n\t"
+        "25:\n\t"
         "s_branch 5f\n\t"
         "4:\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        "v_sub_f32 v40, v52, %[fpx]\n\t"
         "v_sub_f32 v41, v53, %[fpy]\n\t"
+        "v_mul_f32 v39, v56, v41\n\t"
+        "v_fma_f32 v39, v39, v41, v58\n\t"
+        "s_bitcmp1_b64 %[ma], %[ib]\n\t"
+        "s_cbranch_scc0 28f\n\t"
+        "v_sub_f32 v40, v52, %[fpxa]\n\t"
         "v_mul_f32 v62, v54, v40\n\t"
         "v_fma_f32 v62, v55, v41, v62\n\t"
-        "v_mul_f32 v63, v56, v41\n\t"
-        "v_fma_f32 v63, v63, v41, v58\n\t"
-        "v_fma_f32 v62, v40, v62, v63\n\t"
+        "v_fma_f32 v62, v40, v62, v39\n\t"
         "v_exp_f32 v63, v62\n\t"
-        "s_bitcmp1_b64 %[fast], %[ib]\n\t"
-        "s_cbranch_scc1 16f\n\t"
+        "s_bitcmp1_b64 %[fa], %[ib]\n\t"
+        "s_cbranch_scc1 29f\n\t"
         "v_cmpx_le_f32 vcc, v62, v58\n\t"
         "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
-        "v_mul_f32 v40, %[T], v63\n\t"
-        "v_fma_f32 %[Cr], v40, v59, %[Cr]\n\t"
-        "v_fma_f32 %[Cg], v40, v60, %[Cg]\n\t"
-        "v_fma_f32 %[Cb], v40, v61, %[Cb]\n\t"
-        "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
+        "v_mul_f32 v40, %[Ta], v63\n\t"
+        "v_fma_f32 %[Cra], v40, v59, %[Cra]\n\t"
+        "v_fma_f32 %[Cga], v40, v60, %[Cga]\n\t"
+        "v_fma_f32 %[Cba], v40, v61, %[Cba]\n\t"
+        "v_fma_f32 %[Ta], -%[Ta], v63, %[Ta]\n\t"
         "s_mov_b64 exec, -1\n\t"
-        "s_branch 17f\n\t"
-        "16:\n\t"
+        "s_branch 30f\n\t"
+        "29:\n\t"
         "s_nop 0\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
-        "v_mul_f32 v40, %[T], v63\n\t"
-        "v_fma_f32 %[Cr], v40, v59, %[Cr]\n\t"
-        "v_fma_f32 %[Cg], v40, v60, %[Cg]\n\t"
-        "v_fma_f32 %[Cb], v40, v61, %[Cb]\n\t"
-        "v_fma_f32 %[T], -%[T], v63, %[T]\n\t"
+        "v_mul_f32 v40, %[Ta], v63\n\t"
+        "v_fma_f32 %[Cra], v40, v59, %[Cra]\n\t"
+        "v_fma_f32 %[Cga], v40, v60, %[Cga]\n\t"
+        "v_fma_f32 %[Cba], v40, v61, %[Cba]\n\t"
+        "v_fma_f32 %[Ta], -%[Ta], v63, %[Ta]\n\t"
         "s_mov_b64 exec, -1\n\t"
-        "17:\n\t"
+        "30:\n\t"
+        "28:\n\t"
+        "s_bitcmp1_b64 %[mb], %[ib]\n\t"
+        "s_cbranch_scc0 31f\n\t"
+        "v_sub_f32 v40, v52, %[fpxb]\n\t"
+        "v_mul_f32 v62, v54, v40\n\t"
+        "v_fma_f32 v62, v55, v41, v62\n\t"
+        "v_fma_f32 v62, v40, v62, v39\n\t"
+        "v_exp_f32 v63, v62\n\t"
+        "s_bitcmp1_b64 %[fb], %[ib]\n\t"
+        "s_cbranch_scc1 32f\n\t"
+        "v_cmpx_le_f32 vcc, v62, v58\n\t"
+        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[Tb], v63\n\t"
+        "v_fma_f32 %[Crb], v40, v59, %[Crb]\n\t"
+        "v_fma_f32 %[Cgb], v40, v60, %[Cgb]\n\t"
+        "v_fma_f32 %[Cbb], v40, v61, %[Cbb]\n\t"
+        "v_fma_f32 %[Tb], -%[Tb], v63, %[Tb]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 33f\n\t"
+        "32:\n\t"
+        "s_nop 0\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[Tb], v63\n\t"
+        "v_fma_f32 %[Crb], v40, v59, %[Crb]\n\t"
+        "v_fma_f32 %[Cgb], v40, v60, %[Cgb]\n\t"
+        "v_fma_f32 %[Cbb], v40, v61, %[Cbb]\n\t"
+        "v_fma_f32 %[Tb], -%[Tb], v63, %[Tb]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "33:\n\t"
+        "31:\n\t"
         "5:\n\t"
-        : [T] "+v"(T), [Cr] "+v"(Cr), [Cg] "+v"(Cg), [Cb] "+v"(Cb), [m] "+s"(m), [ia] "=&s"(ia), [ib] "=&s"(ib)
-        : [base] "v"(lds_chunk), [fpx] "v"(fpx), [fpy] "v"(fpy), [fast] "s"(fast)
-        : "vcc", "scc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",
-          "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+        : [Ta] "+v"(Ta), [Cra] "+v"(Cra), [Cga] "+v"(Cga), [Cba] "+v"(Cba), [Tb] "+v"(Tb), [Crb] "+v"(Crb), [Cgb] "+v"(Cgb),
+          [Cbb] "+v"(Cbb), [m] "+s"(m), [ia] "=&s"(ia), [ib] "=&s"(ib)
+        : [base] "v"(lds_chunk), [fpxa] "v"(fpxa), [fpxb] "v"(fpxb), [fpy] "v"(fpy), [ma] "s"(ma), [mb] "s"(mb), [fa] "s"(fa), [fb] "s"(fb)
+        : "vcc", "scc", "memory", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
+          "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 }
 
 // Tile launch order.  Group g = tile rows g, g+8, ... of the shard (one XCD's share).  One workgroup per
@@ -292,12 +432,12 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict
     }
 }
 
-template <bool ASM_WALK>
+// The plain-C statement of the blend (GsrOptions.blend_impl = 1): one 256-thread workgroup per tile, wave = 8x8 quadrant, lane =
+// pixel.  The reference for the hand-scheduled kernel below, and what round 1 shipped.
 __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
 {
     __shared__ float4 srec[3][256];  // staged records, one plane per 16-B part: q0 at +0, q1 at +4096, q2 at +8192 bytes
     float4 *const s0 = srec[0], *const s1 = srec[1], *const s2 = srec[2];
-    const unsigned lds_rec = (unsigned)(size_t)&srec[0][0];  // LDS byte address: the low half of the flat pointer
     __shared__ int s_done;
 
     const int tile = a.order[blockIdx.x];
@@ -337,40 +477,28 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
         const int nb = min(256u, range.y - batch);
         for (int chunk = 0; chunk < nb; chunk += 64) {
             const int e = chunk + lane;
-            unsigned long long m, fast = 0;
-            if (ASM_WALK) {
-                FootprintClass fc = {false, false};
-                if (e < nb) fc = footprint_classify(s0[e], s1[e], s2[e].x, qx0, qx1, qy0, qy1);
-                m = __ballot(fc.hit);
-                fast = __ballot(fc.fast);
-            } else {
-                const bool hit = e < nb && footprint_hits_rect(s0[e], s1[e], qx0, qx1, qy0, qy1);
-                m = __ballot(hit);
-            }
+            const bool hit = e < nb && footprint_hits_rect(s0[e], s1[e], qx0, qx1, qy0, qy1);
+            unsigned long long m = __ballot(hit);
             evaluated += (uint32_t)__popcll(m);
-            if (ASM_WALK) {
-                if (m) blend_walk_asm(m, fast, lds_rec + (unsigned)chunk * 16u, fpx, fpy, T, Cr, Cg, Cb);
-            } else {
-                // plain form: two survivors per trip so that the second one's LDS reads overlap the first one's arithmetic
-                while (m) {
-                    const int k0 = chunk + (__ffsll((long long)m) - 1);
+            // two survivors per trip so that the second one's LDS reads overlap the first one's arithmetic
+            while (m) {
+                const int k0 = chunk + (__ffsll((long long)m) - 1);
+                m &= m - 1;
+                const float2 ga = *reinterpret_cast<const float2 *>(&s0[k0]);  // wave-uniform address: LDS broadcast
+                const float4 ca = s1[k0];
+                const float4 oa = s2[k0];
+                asm volatile("" ::"v"(ca.w));  // keep the read a ds_read_b128 (4 LDS cycles); a b96 costs 8
+                if (m) {
+                    const int k1 = chunk + (__ffsll((long long)m) - 1);
                     m &= m - 1;
-                    const float2 ga = *reinterpret_cast<const float2 *>(&s0[k0]);  // wave-uniform address: LDS broadcast
-                    const float4 ca = s1[k0];
-                    const float4 oa = s2[k0];
-                    asm volatile("" ::"v"(ca.w));  // keep the read a ds_read_b128 (4 LDS cycles); a b96 costs 8
-                    if (m) {
-                        const int k1 = chunk + (__ffsll((long long)m) - 1);
-                        m &= m - 1;
-                        const float2 gb = *reinterpret_cast<const float2 *>(&s0[k1]);
-                        const float4 cb = s1[k1];
-                        const float4 ob = s2[k1];
-                        asm volatile("" ::"v"(cb.w));
-                        blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
-                        blend_one(gb, cb, ob, fpx, fpy, T, Cr, Cg, Cb);
-                    } else {
-                        blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
-                    }
+                    const float2 gb = *reinterpret_cast<const float2 *>(&s0[k1]);
+                    const float4 cb = s1[k1];
+                    const float4 ob = s2[k1];
+                    asm volatile("" ::"v"(cb.w));
+                    blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
+                    blend_one(gb, cb, ob, fpx, fpy, T, Cr, Cg, Cb);
+                } else {
+                    blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
                 }
             }
             if (__all(T <= a.early_T)) {
@@ -396,6 +524,94 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
                             : a.layout == 0 ? (size_t)py * a.W + px
                                             : (size_t)(((ty - a.row_begin) / a.row_step) * 16 + (py - ty * 16)) * a.W + px;
             a.out_T[ot] = drawn ? T : 1.0f;
+        }
+    }
+}
+
+// The product kernel (GsrOptions.blend_impl = 0): one 128-thread workgroup per 16x16 tile, wave w = the 16x8 half (pixel rows
+// 8w .. 8w+7), a lane = TWO pixels 8 columns apart, one in each 8x8 quadrant of the half.  Same lists, same per-quadrant
+// classification and saturation tests, same arithmetic as blend_kernel; 128 entries staged per batch.
+__global__ __launch_bounds__(128, 8) void blend_half_kernel(BlendArgs a)
+{
+    constexpr int BATCH = 128;
+    __shared__ float4 srec[3][BATCH];  // planes 2048 B apart (gen_blend_walk.py half)
+    float4 *const s0 = srec[0], *const s1 = srec[1], *const s2 = srec[2];
+    const unsigned lds_rec = (unsigned)(size_t)&srec[0][0];
+    __shared__ int s_done;
+
+    const int tile = a.order[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *stat = a.stats + (size_t)blockIdx.x * BLEND_STAT_WORDS;
+    if (tile < 0) {  // uniform: empty launch slot
+        if (tid < 5) stat[tid] = 0;
+        return;
+    }
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int qx = tx * 16, qy = ty * 16 + wave * 8;
+    const int px = qx + (lane & 7), py = qy + (lane >> 3);  // pixel A; pixel B = (px + 8, py)
+    const float fpxA = (float)px, fpxB = (float)(px + 8), fpy = (float)py;
+    const float xa0 = (float)qx, xa1 = (float)(qx + 7), xb0 = (float)(qx + 8), xb1 = (float)(qx + 15);
+    const float qy0 = (float)qy, qy1 = (float)(qy + 7);
+
+    const uint2 range = a.ranges[tile];
+    float TA = 1.0f, CrA = 0.0f, CgA = 0.0f, CbA = 0.0f;
+    float TB = 1.0f, CrB = 0.0f, CgB = 0.0f, CbB = 0.0f;
+    bool doneA = false, doneB = false;  // wave-uniform: quadrant saturated
+    uint32_t evaluated = 0;             // wave-uniform
+    uint32_t fetched = 0;               // workgroup-uniform
+    if (tid == 0) s_done = 0;
+
+    for (uint32_t batch = range.x; batch < range.y; batch += BATCH) {
+        __syncthreads();  // previous batch fully consumed (and s_done initialised)
+        if (s_done == 2) break;  // uniform: both waves saturated
+        const uint32_t i = batch + tid;
+        fetched += min((uint32_t)BATCH, range.y - batch);
+        if (i < range.y) {
+            const GaussRec *r = a.rec + a.pval[i];
+            s0[tid] = r->q0;
+            s1[tid] = r->q1;
+            s2[tid] = r->q2;
+        }
+        __syncthreads();
+        if (doneA && doneB) continue;
+        const int nb = min((uint32_t)BATCH, range.y - batch);
+        for (int chunk = 0; chunk < nb; chunk += 64) {
+            const int e = chunk + lane;
+            FootprintClass fa = {false, false}, fb = {false, false};
+            if (e < nb) {
+                const float4 q0 = s0[e], q1 = s1[e];
+                const float L = s2[e].x;
+                fa = footprint_classify(q0, q1, L, xa0, xa1, qy0, qy1);
+                fb = footprint_classify(q0, q1, L, xb0, xb1, qy0, qy1);
+            }
+            const unsigned long long mA = doneA ? 0ull : __ballot(fa.hit), mB = doneB ? 0ull : __ballot(fb.hit);
+            const unsigned long long fA = __ballot(fa.fast), fB = __ballot(fb.fast);
+            evaluated += (uint32_t)__popcll(mA) + (uint32_t)__popcll(mB);
+            if (mA | mB)
+                blend_walk2_asm(mA | mB, mA, mB, fA, fB, lds_rec + (unsigned)chunk * 16u, fpxA, fpxB, fpy, TA, CrA, CgA, CbA, TB, CrB, CgB, CbB);
+            if (!doneA && __all(TA <= a.early_T)) doneA = true;
+            if (!doneB && __all(TB <= a.early_T)) doneB = true;
+            if (doneA && doneB) {
+                if (lane == 0) atomicAdd(&s_done, 1);
+                break;
+            }
+        }
+    }
+
+    if (lane == 0) { stat[wave] = evaluated; stat[2 + wave] = 0; }
+    if (tid == 0) stat[4] = fetched;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int x = px + 8 * h;
+        const float T = h ? TB : TA, Cr = h ? CrB : CrA, Cg = h ? CgB : CgA, Cb = h ? CbB : CbA;
+        if (x < a.W && py < a.H) {
+            const bool drawn = x < a.xlim && py < a.ylim;  // Q1: last column / row stay black, T stays 1
+            const float r = drawn ? Cr : 0.0f, g = drawn ? Cg : 0.0f, b = drawn ? Cb : 0.0f;
+            const size_t pix = a.layout == 0 ? (size_t)py * a.W + x                                           // image [H,W,3]
+                             : a.layout == 1 ? (size_t)x * a.H + py                                           // screen [W,H,3]
+                                             : (size_t)(((ty - a.row_begin) / a.row_step) * 16 + (py - ty * 16)) * a.W + x;  // strip
+            store_rgb(a, pix * 3, r, g, b);
+            if (a.out_T) a.out_T[pix] = drawn ? T : 1.0f;
         }
     }
 }
@@ -428,8 +644,8 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
                        slots_per_group, ws.tile_order,
                        (uint32_t)(reinterpret_cast<const char *>(ws.blend_stats) - reinterpret_cast<const char *>(ws.ctrl)));
     if (opts.blend_impl == 2) return launch_blend_mfma(a, 8u * (unsigned)slots_per_group, s);
-    if (opts.blend_impl == 1) hipLaunchKernelGGL(blend_kernel<false>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(blend_kernel<true>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
+    if (opts.blend_impl == 1) hipLaunchKernelGGL(blend_kernel, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(blend_half_kernel, dim3(8u * (unsigned)slots_per_group), dim3(128), 0, s, a);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }
