@@ -24,10 +24,11 @@ def guarded_or_not(fastmask, idx, o0, st):
     return [f"s_bitcmp1_b64 {fastmask}, {idx}", f"s_cbranch_scc1 {lf}f"] + full + [f"s_branch {lj}f", f"{lf}:"] + fast + [f"{lj}:"]
 
 
-def load(idx, addr, g0, c0, o0, plane):
+def load(idx, addr, g0, c0, o0):
+    # %[p1] / %[p2]: byte offsets of the record's second and third LDS plane (immediates: BATCH * 16, BATCH * 32)
     return [f"s_ff1_i32_b64 {idx}, %[m]", f"s_bitset0_b64 %[m], {idx}", f"v_lshl_add_u32 v{addr}, {idx}, 4, %[base]",
-            f"ds_read_b64 v[{g0}:{g0 + 1}], v{addr}", f"ds_read_b128 v[{c0}:{c0 + 3}], v{addr} offset:{plane}",
-            f"ds_read_b128 v[{o0}:{o0 + 3}], v{addr} offset:{2 * plane}"]
+            f"ds_read_b64 v[{g0}:{g0 + 1}], v{addr}", f"ds_read_b128 v[{c0}:{c0 + 3}], v{addr} offset:%[p1]",
+            f"ds_read_b128 v[{o0}:{o0 + 3}], v{addr} offset:%[p2]"]
 
 
 def ev_half(idx, g0, c0, o0):
@@ -43,16 +44,16 @@ def ev_half(idx, g0, c0, o0):
     return out
 
 
-def walk(ev, plane):
+def walk(ev):
     A, B = (42, 44, 48), (52, 54, 58)
     IA, IB = "%[ia]", "%[ib]"
-    lines = ["s_waitcnt lgkmcnt(0)"] + load(IA, 40, *A, plane)
-    lines += ["1:", "s_cmp_eq_u64 %[m], 0", "s_cbranch_scc1 3f"] + load(IB, 41, *B, plane) + ["s_waitcnt lgkmcnt(3)"] + ev(IA, *A)
-    lines += ["s_cmp_eq_u64 %[m], 0", "s_cbranch_scc1 4f"] + load(IA, 40, *A, plane) + ["s_waitcnt lgkmcnt(3)"] + ev(IB, *B) + ["s_branch 1b"]
+    lines = ["s_waitcnt lgkmcnt(0)"] + load(IA, 40, *A)
+    lines += ["1:", "s_cmp_eq_u64 %[m], 0", "s_cbranch_scc1 3f"] + load(IB, 41, *B) + ["s_waitcnt lgkmcnt(3)"] + ev(IA, *A)
+    lines += ["s_cmp_eq_u64 %[m], 0", "s_cbranch_scc1 4f"] + load(IA, 40, *A) + ["s_waitcnt lgkmcnt(3)"] + ev(IB, *B) + ["s_branch 1b"]
     lines += ["3:", "s_waitcnt lgkmcnt(0)"] + ev(IA, *A) + ["s_branch 5f"]
     lines += ["4:", "s_waitcnt lgkmcnt(0)"] + ev(IB, *B) + ["5:"]
     return lines
 
 
-lines = walk(ev_half, 2048)
+lines = walk(ev_half)
 print("\n".join('        "%s\\n\\t"' % l for l in lines))

@@ -17,7 +17,7 @@
 //     approximation of the reference's "blend every gaussian" (Q5): transmittance only ever shrinks, and once it
 //     has underflowed to 0.0f (a few dozen near-opaque layers) alpha*T*rgb = 0 and T stays 0 — the remaining
 //     entries cannot change a bit.  early_out_T > 0 (INRIA uses 1e-4) is the usual bounded approximation.
-// Two kernels share this: blend_kernel, the plain-C statement (blend_impl = 1), and blend_half_kernel, the product, whose
+// Two kernels share this: blend_kernel, the plain-C statement (blend_impl = 1), and blend_walk_kernel, the product, whose
 // inner walk is one hand-scheduled asm statement — bit-identical frames (its comment has the measurements).
 //
 // Launch order: list lengths are heavy-tailed (longest ~3.5x the mean) and a frame is only ~4 rounds of
@@ -87,6 +87,7 @@ __device__ __forceinline__ void blend_one(const float2 g, const float4 c, const 
 // COMPILER's walk (+4 %: its register copies and selects ate the saved reads).
 // The text below is generated by tools/gen_blend_walk.py.  lds_chunk = LDS byte address of the chunk's first record
 // (plane 0; the planes are 2048 B apart), identical in every lane.
+template <int PLANE>  // bytes between the LDS planes of the staged records = 16 * entries per batch
 __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned long long ma, unsigned long long mb, unsigned long long fa,
                                                 unsigned long long fb, unsigned lds_chunk, float fpxa, float fpxb, float fpy, float &Ta,
                                                 float &Cra, float &Cga, float &Cba, float &Tb, float &Crb, float &Cgb, float &Cbb)
@@ -98,8 +99,8 @@ __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned l
         "s_bitset0_b64 %[m], %[ia]\n\t"
         "v_lshl_add_u32 v40, %[ia], 4, %[base]\n\t"
         "ds_read_b64 v[42:43], v40\n\t"
-        "ds_read_b128 v[44:47], v40 offset:2048\n\t"
-        "ds_read_b128 v[48:51], v40 offset:4096\n\t"
+        "ds_read_b128 v[44:47], v40 offset:%[p1]\n\t"
+        "ds_read_b128 v[48:51], v40 offset:%[p2]\n\t"
         "1:\n\t"
         "s_cmp_eq_u64 %[m], 0\n\t"
         "s_cbranch_scc1 3f\n\t"
@@ -107,8 +108,8 @@ __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned l
         "s_bitset0_b64 %[m], %[ib]\n\t"
         "v_lshl_add_u32 v41, %[ib], 4, %[base]\n\t"
         "ds_read_b64 v[52:53], v41\n\t"
-        "ds_read_b128 v[54:57], v41 offset:2048\n\t"
-        "ds_read_b128 v[58:61], v41 offset:4096\n\t"
+        "ds_read_b128 v[54:57], v41 offset:%[p1]\n\t"
+        "ds_read_b128 v[58:61], v41 offset:%[p2]\n\t"
         "s_waitcnt lgkmcnt(3)\n\t"
         "v_sub_f32 v41, v43, %[fpy]\n\t"
         "v_mul_f32 v39, v46, v41\n\t"
@@ -179,8 +180,8 @@ __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned l
         "s_bitset0_b64 %[m], %[ia]\n\t"
         "v_lshl_add_u32 v40, %[ia], 4, %[base]\n\t"
         "ds_read_b64 v[42:43], v40\n\t"
-        "ds_read_b128 v[44:47], v40 offset:2048\n\t"
-        "ds_read_b128 v[48:51], v40 offset:4096\n\t"
+        "ds_read_b128 v[44:47], v40 offset:%[p1]\n\t"
+        "ds_read_b128 v[48:51], v40 offset:%[p2]\n\t"
         "s_waitcnt lgkmcnt(3)\n\t"
         "v_sub_f32 v41, v53, %[fpy]\n\t"
         "v_mul_f32 v39, v56, v41\n\t"
@@ -380,7 +381,8 @@ __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned l
         "5:\n\t"
         : [Ta] "+v"(Ta), [Cra] "+v"(Cra), [Cga] "+v"(Cga), [Cba] "+v"(Cba), [Tb] "+v"(Tb), [Crb] "+v"(Crb), [Cgb] "+v"(Cgb),
           [Cbb] "+v"(Cbb), [m] "+s"(m), [ia] "=&s"(ia), [ib] "=&s"(ib)
-        : [base] "v"(lds_chunk), [fpxa] "v"(fpxa), [fpxb] "v"(fpxb), [fpy] "v"(fpy), [ma] "s"(ma), [mb] "s"(mb), [fa] "s"(fa), [fb] "s"(fb)
+        : [base] "v"(lds_chunk), [fpxa] "v"(fpxa), [fpxb] "v"(fpxb), [fpy] "v"(fpy), [ma] "s"(ma), [mb] "s"(mb), [fa] "s"(fa), [fb] "s"(fb),
+          [p1] "i"(PLANE), [p2] "i"(2 * PLANE)
         : "vcc", "scc", "memory", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
           "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 }
@@ -528,15 +530,20 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
     }
 }
 
-// The product kernel (GsrOptions.blend_impl = 0): one 128-thread workgroup per 16x16 tile, wave w = the 16x8 half (pixel rows
-// 8w .. 8w+7), a lane = TWO pixels 8 columns apart, one in each 8x8 quadrant of the half.  Same lists, same per-quadrant
-// classification and saturation tests, same arithmetic as blend_kernel; 128 entries staged per batch.
-__global__ __launch_bounds__(128, 8) void blend_half_kernel(BlendArgs a)
+// The product kernel (GsrOptions.blend_impl = 0).  QPW = 2: one 128-thread workgroup per 16x16 tile, wave w = the 16x8 half
+// (pixel rows 8w .. 8w+7), a lane = TWO pixels 8 columns apart, one in each 8x8 quadrant of the half; 128 entries staged per
+// batch.  QPW = 1: 256 threads, wave = one quadrant, 256 entries per batch — the same walk with quadrant B switched off.
+// Two quadrants per wave share LDS reads and part of the quadratic (7-8 % faster on a whole frame), but with few tiles per CU
+// (a multi-GPU rank's shard) four waves per tile fill the SIMDs better and halve the per-tile critical path (G = 8 shard:
+// 0.52 vs 0.65 ms), so launch_blend picks by tile count.  Same lists, same per-quadrant classification and saturation tests,
+// same arithmetic as blend_kernel.
+template <int QPW>
+__global__ __launch_bounds__(256 / QPW, 8) void blend_walk_kernel(BlendArgs a)
 {
-    constexpr int BATCH = 128;
-    __shared__ float4 srec[3][BATCH];  // planes 2048 B apart (gen_blend_walk.py half)
+    constexpr int THREADS = 256 / QPW, BATCH = THREADS, WAVES = THREADS / 64;
+    __shared__ float4 srec[3][BATCH];  // planes BATCH * 16 B apart
     float4 *const s0 = srec[0], *const s1 = srec[1], *const s2 = srec[2];
-    const unsigned lds_rec = (unsigned)(size_t)&srec[0][0];
+    const unsigned lds_rec = (unsigned)(size_t)&srec[0][0];  // LDS byte address: the low half of the flat pointer
     __shared__ int s_done;
 
     const int tile = a.order[blockIdx.x];
@@ -547,8 +554,8 @@ __global__ __launch_bounds__(128, 8) void blend_half_kernel(BlendArgs a)
         return;
     }
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int qx = tx * 16, qy = ty * 16 + wave * 8;
-    const int px = qx + (lane & 7), py = qy + (lane >> 3);  // pixel A; pixel B = (px + 8, py)
+    const int qx = tx * 16 + (QPW == 1 ? (wave & 1) * 8 : 0), qy = ty * 16 + (QPW == 1 ? wave >> 1 : wave) * 8;
+    const int px = qx + (lane & 7), py = qy + (lane >> 3);  // pixel A; QPW = 2: pixel B = (px + 8, py)
     const float fpxA = (float)px, fpxB = (float)(px + 8), fpy = (float)py;
     const float xa0 = (float)qx, xa1 = (float)(qx + 7), xb0 = (float)(qx + 8), xb1 = (float)(qx + 15);
     const float qy0 = (float)qy, qy1 = (float)(qy + 7);
@@ -556,14 +563,14 @@ __global__ __launch_bounds__(128, 8) void blend_half_kernel(BlendArgs a)
     const uint2 range = a.ranges[tile];
     float TA = 1.0f, CrA = 0.0f, CgA = 0.0f, CbA = 0.0f;
     float TB = 1.0f, CrB = 0.0f, CgB = 0.0f, CbB = 0.0f;
-    bool doneA = false, doneB = false;  // wave-uniform: quadrant saturated
-    uint32_t evaluated = 0;             // wave-uniform
-    uint32_t fetched = 0;               // workgroup-uniform
+    bool doneA = false, doneB = QPW == 1;  // wave-uniform: quadrant saturated (B does not exist when QPW = 1)
+    uint32_t evaluated = 0;                // wave-uniform
+    uint32_t fetched = 0;                  // workgroup-uniform
     if (tid == 0) s_done = 0;
 
     for (uint32_t batch = range.x; batch < range.y; batch += BATCH) {
         __syncthreads();  // previous batch fully consumed (and s_done initialised)
-        if (s_done == 2) break;  // uniform: both waves saturated
+        if (s_done == WAVES) break;  // uniform: every wave saturated
         const uint32_t i = batch + tid;
         fetched += min((uint32_t)BATCH, range.y - batch);
         if (i < range.y) {
@@ -582,15 +589,16 @@ __global__ __launch_bounds__(128, 8) void blend_half_kernel(BlendArgs a)
                 const float4 q0 = s0[e], q1 = s1[e];
                 const float L = s2[e].x;
                 fa = footprint_classify(q0, q1, L, xa0, xa1, qy0, qy1);
-                fb = footprint_classify(q0, q1, L, xb0, xb1, qy0, qy1);
+                if (QPW == 2) fb = footprint_classify(q0, q1, L, xb0, xb1, qy0, qy1);
             }
-            const unsigned long long mA = doneA ? 0ull : __ballot(fa.hit), mB = doneB ? 0ull : __ballot(fb.hit);
-            const unsigned long long fA = __ballot(fa.fast), fB = __ballot(fb.fast);
+            const unsigned long long mA = doneA ? 0ull : __ballot(fa.hit), mB = (QPW == 1 || doneB) ? 0ull : __ballot(fb.hit);
+            const unsigned long long fA = __ballot(fa.fast), fB = QPW == 1 ? 0ull : __ballot(fb.fast);
             evaluated += (uint32_t)__popcll(mA) + (uint32_t)__popcll(mB);
             if (mA | mB)
-                blend_walk2_asm(mA | mB, mA, mB, fA, fB, lds_rec + (unsigned)chunk * 16u, fpxA, fpxB, fpy, TA, CrA, CgA, CbA, TB, CrB, CgB, CbB);
+                blend_walk2_asm<BATCH * 16>(mA | mB, mA, mB, fA, fB, lds_rec + (unsigned)chunk * 16u, fpxA, fpxB, fpy, TA, CrA, CgA, CbA, TB,
+                                            CrB, CgB, CbB);
             if (!doneA && __all(TA <= a.early_T)) doneA = true;
-            if (!doneB && __all(TB <= a.early_T)) doneB = true;
+            if (QPW == 2 && !doneB && __all(TB <= a.early_T)) doneB = true;
             if (doneA && doneB) {
                 if (lane == 0) atomicAdd(&s_done, 1);
                 break;
@@ -598,10 +606,13 @@ __global__ __launch_bounds__(128, 8) void blend_half_kernel(BlendArgs a)
         }
     }
 
-    if (lane == 0) { stat[wave] = evaluated; stat[2 + wave] = 0; }
+    if (lane == 0) {
+        stat[wave] = evaluated;
+        if (QPW == 2) stat[2 + wave] = 0;
+    }
     if (tid == 0) stat[4] = fetched;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < QPW; ++h) {
         const int x = px + 8 * h;
         const float T = h ? TB : TA, Cr = h ? CrB : CrA, Cg = h ? CgB : CgA, Cb = h ? CbB : CbA;
         if (x < a.W && py < a.H) {
@@ -615,6 +626,9 @@ __global__ __launch_bounds__(128, 8) void blend_half_kernel(BlendArgs a)
         }
     }
 }
+
+// two quadrants per wave from this many tiles per launch on (measured: 4080 tiles better with two, 2040 with one); below, one quadrant per wave (see blend_walk_kernel)
+constexpr int BLEND_HALF_MIN_TILES = 3000;
 
 int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, const uint32_t *lists, void *out_image,
                  float *out_T, hipStream_t s)
@@ -645,7 +659,8 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
                        (uint32_t)(reinterpret_cast<const char *>(ws.blend_stats) - reinterpret_cast<const char *>(ws.ctrl)));
     if (opts.blend_impl == 2) return launch_blend_mfma(a, 8u * (unsigned)slots_per_group, s);
     if (opts.blend_impl == 1) hipLaunchKernelGGL(blend_kernel, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(blend_half_kernel, dim3(8u * (unsigned)slots_per_group), dim3(128), 0, s, a);
+    else if (a.rows * a.tiles_x >= BLEND_HALF_MIN_TILES) hipLaunchKernelGGL(blend_walk_kernel<2>, dim3(8u * (unsigned)slots_per_group), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(blend_walk_kernel<1>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }
