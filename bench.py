@@ -309,7 +309,7 @@ def main():
         achieved = blend_bytes / (stage[2] * 1e-3) / 1e9
         prof = pmc_profile(args.workload) if world == 1 else {}
         result["roofline"] = {
-            "kernel": "gsr::blend_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": "gsr::blend_walk_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": prof.get("blend_kernel_bytes_per_launch"),
             "algorithmic_bytes_per_launch": blend_bytes, "avg_kernel_ms": stage[2],
             "limiter": "on-chip: VALU issue + LDS reads (exact per-pixel evaluation: ~70 flop and 6.4 exp per algorithmic byte, "

@@ -32,7 +32,7 @@ def main():
     for f in sorted(glob.glob(os.path.join(src, "pmc_*_counter_collection.csv"))):
         per = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            kern = "blend_kernel" if "blend_kernel<" in r["Kernel_Name"] or "blend_kernel(" in r["Kernel_Name"] else ("preprocess_kernel" if "preprocess_kernel" in r["Kernel_Name"] else r["Kernel_Name"][:40])
+            kern = "blend_kernel" if ("blend_walk_kernel" in r["Kernel_Name"] or "blend_kernel" in r["Kernel_Name"]) else ("preprocess_kernel" if "preprocess_kernel" in r["Kernel_Name"] else r["Kernel_Name"][:40])
             per[kern][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for kern, cs in per.items():
             for c, v in cs.items():
@@ -68,7 +68,7 @@ def main():
             print("no per-entry figures:", e)
         if "GRBM_GUI_ACTIVE" in c:
             cyc = c["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
-            rows = [r for r in csv.DictReader(open(out + "_kernel_stats.csv")) if "blend_kernel" in r["Name"]]
+            rows = [r for r in csv.DictReader(open(out + "_kernel_stats.csv")) if "blend_walk_kernel" in r["Name"] or "blend_kernel" in r["Name"]]
             if rows:
                 t["clock_ghz"] = cyc / float(rows[0]["AverageNs"])
             if "SQ_LDS_IDX_ACTIVE" in c:
