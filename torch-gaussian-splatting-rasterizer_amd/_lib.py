@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgsr.so")
+LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(_HERE, "csrc", "libgsr.so")  # the override is for A/B tooling only
 
 GSR_OK = 0
 GSR_ERR_BAD_ARG = -1
