@@ -181,7 +181,7 @@ def test_configs3_sharded_frame_over_gloo_ranks_sharing_the_gpu(G):
 def test_configs3_sharded_frame_over_rccl(G):
     """One rank per GPU, RCCL gather over xGMI: frames bit-identical to the single-GPU frame, for several frames in a row
     (pins the buffer-reuse ordering between gather_async on the communicator stream and the next frame's render)."""
-    ranks = min(torch.cuda.device_count(), 8)
+    ranks = min(torch.cuda.device_count(), 4)  # + this pytest process: within the box's limit of 6 GPU processes
     p = _run_dist_check("nccl", ranks)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "DIST_CHECK_OK" in p.stdout
