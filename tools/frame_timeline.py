@@ -11,7 +11,7 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     arg = sys.argv[2] if len(sys.argv) > 2 else "5"
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    starts = [i for i, r in enumerate(rows) if "preprocess_kernel" in r["Kernel_Name"]]
+    starts = [i for i, r in enumerate(rows) if "preprocess_kernel" in r["Kernel_Name"] or "shard_preprocess_kernel" in r["Kernel_Name"]]
     if arg.startswith("+"):
         s, e = starts[int(arg)], starts[int(arg) + 1]
     else:

@@ -243,7 +243,7 @@ int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // depth order: pass 0 drops culled gaussians and leaves V in ctrl; 3 passes on ordinary scenes (sort.hip)
-    rc = launch_depth_sort(ws, rect_fits_8bit(ws), s);
+    rc = launch_depth_sort(ws, rect_fits_8bit(ws), shard_compact(*opts), s);
     if (rc) return rc;
     // pairs in depth order, stably sorted by tile -> per-tile lists and their ranges; E in ctrl
     return launch_binning(*opts, ws, s);

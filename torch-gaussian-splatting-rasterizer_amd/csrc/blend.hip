@@ -549,6 +549,9 @@ __global__ __launch_bounds__(256 / QPW, 8) void blend_walk_kernel(BlendArgs a)
     const int tile = a.order[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t *stat = a.stats + (size_t)blockIdx.x * BLEND_STAT_WORDS;
+#ifdef GSR_BLEND_TIMESTAMPS  // tools/blend_wg_times.py: when does every workgroup start and end (100 MHz clock), and where
+    const unsigned long long ts0 = wall_clock64();
+#endif
     if (tile < 0) {  // uniform: empty launch slot
         if (tid < 5) stat[tid] = 0;
         return;
@@ -611,6 +614,14 @@ __global__ __launch_bounds__(256 / QPW, 8) void blend_walk_kernel(BlendArgs a)
         if (QPW == 2) stat[2 + wave] = 0;
     }
     if (tid == 0) stat[4] = fetched;
+#ifdef GSR_BLEND_TIMESTAMPS
+    __syncthreads();
+    if (tid == 0) {
+        stat[5] = (uint32_t)ts0;
+        stat[6] = (uint32_t)wall_clock64();
+        stat[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID (wave/SIMD/CU/SH/SE), whole register
+    }
+#endif
 #pragma unroll
     for (int h = 0; h < QPW; ++h) {
         const int x = px + 8 * h;

@@ -28,6 +28,8 @@ struct FrameCtrl {
     uint32_t sort_key_bits;  //   val[sort_passes & 1]; significant bits of key - bits(0.2f); digit width of the passes
     uint32_t sort_bits_rest; //   after the first.  Written by the pass-0 rowscan.
     uint32_t n_cpairs;       // coarse binning: 32x32-cell pairs that survive the sort's drop (count of the coarse ranges pass)
+    uint32_t n_records;      // multi-GPU shard: records entering the depth sort (= this rank's visible gaussians; preprocess.hip)
+    uint32_t _pad0;
     // ---- everything below survives the per-frame clear ----
     uint32_t batch_overflow; // sticky across the views of gsr_render_batch
     uint32_t batch_need;     // largest D seen in the batch
@@ -105,7 +107,7 @@ int launch_rasterize_gaussian(int64_t g, const int64_t *bboxes, float *screen, c
 
 // Depth order (sort.hip): stable LSD radix sort of the depth keys; leaves V in FrameCtrl.n_visible and the sorted ids (+ packed
 // rects) in val[p] / rect8[p], p = FrameCtrl.sort_passes & 1 (decided on the device from the frame's key range).
-int launch_depth_sort(const Workspace &ws, bool packed_rect, hipStream_t s);
+int launch_depth_sort(const Workspace &ws, bool packed_rect, bool compact_input, hipStream_t s);
 // Stable radix sort of the pair arrays over key bits [first_bit, key_bits); the first pass drops keys >= drop_from and leaves the
 // survivor count in *n_out.  in_buf / *result_buf: which of pkey[]/pval[] holds input / output.
 int launch_pair_sort(const Workspace &ws, int in_buf, const uint32_t *n_dev, int first_bit, int key_bits, uint32_t drop_from,
@@ -119,6 +121,10 @@ struct TileKeying {
 };
 TileKeying tile_keying(const Workspace &ws);
 inline bool rect_fits_8bit(const Workspace &ws) { return ws.tiles_x <= 256 && ws.tiles_y <= 256; }
+// A multi-GPU shard's preprocess (preprocess.hip) hands the depth sort a compact list of (key, id, rect) records of the rank's
+// visible gaussians instead of one key per gaussian.  Progressive frames (draw_limit) rank ALL gaussians the reference
+// draws, so they take the whole-frame path.
+inline bool shard_compact(const GsrOptions &o) { return o.tile_row_step > 1 && o.draw_limit == 0; }
 // Stage 2b: pairs of the depth-sorted gaussians -> per-tile depth-ordered lists + ranges[] (count, scan, emit, sort, ranges,
 // and with coarse binning the expansion).
 int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s);

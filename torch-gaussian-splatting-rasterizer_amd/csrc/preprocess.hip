@@ -25,39 +25,44 @@ struct Cam {
     int W, H;
 };
 
-template <bool DEBUG, bool SH16, bool SHARD>
-__global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, GaussRec *__restrict__ rec,
-                                                         ushort4 *__restrict__ rect, uint32_t *__restrict__ rect8, uint32_t *__restrict__ depth_key,
-                                                         GsrDebugOut dbg,
-                                                         uint32_t *__restrict__ ctrl_words, int ctrl_reset_words, int packed_rect)
+// What the geometry half of the per-gaussian work hands on (to the colour half and to whoever writes the outputs).
+struct GeoOut {
+    bool visible;     // enters this rank's depth sort with a non-empty tile rect
+    bool keep_empty;  // progressive render only: enters the sort with an empty rect (counts in the reference's draw order)
+    uint32_t key;     // IEEE bits of z_cam
+    int tx0, ty0, tx1, ty1;
+    float mx, my, sx, sy, sxy, pthr, op;  // screen mean, conic, culling threshold, opacity: what record_of() needs
+    float p[3];       // the mean (world), for the colour half
+};
+
+// GaussRec.q0, q1 and q2.x of a visible gaussian (q2.yzw is its colour).
+__device__ __forceinline__ void record_of(const GeoOut &g, float4 *q0, float4 *q1, float *log2_op)
 {
-    // frame reset: nothing in this kernel reads FrameCtrl and every later kernel of the frame is stream-ordered behind it,
-    // so workgroup 0 clears the counters here (a hipMemsetAsync costs two blit kernels and a dispatch bubble, ~20 us)
-    if (blockIdx.x == 0)
-        for (int w = threadIdx.x; w < ctrl_reset_words; w += 256) ctrl_words[w] = 0u;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // the literal, not blockDim.x: that would pull in the hidden kernarg block
-    if (i >= sc.n) return;
-    // (the gaussian id is not written: pass 0 of the depth sort synthesises the identity payload, 8 B per gaussian less traffic)
+    const float LOG2E = 1.4426950408889634f;
+    const float A = (-0.5f * g.sx) * LOG2E, B = (-g.sxy) * LOG2E, C = (-0.5f * g.sy) * LOG2E;
+    // -B/(2C), -B/(2A): only used by the culling test, and only when the conic is positive definite (A, C < 0)
+    const float rc = g.pthr < -1e37f ? 0.0f : -0.5f * B / C, ra = g.pthr < -1e37f ? 0.0f : -0.5f * B / A;
+    *q0 = make_float4(g.mx, g.my, rc, ra);
+    *q1 = make_float4(A, B, C, g.pthr);
+    *log2_op = log2f(g.op);
+}
+
+// Geometry of gaussian `i`: everything rasterize.py:354-420 computes per gaussian except the colour.
+template <bool DEBUG>
+__device__ __forceinline__ GeoOut geometry_one(const GsrScene &sc, const Cam &cam, int compat, int no_cull, int row_begin, int row_step,
+                                               int keep_ref_drawn, const GsrDebugOut &dbg, int64_t i)
+{
+    GeoOut g;
+    g.visible = g.keep_empty = false;
     const float p[3] = {sc.means[3 * i], sc.means[3 * i + 1], sc.means[3 * i + 2]};
-    // SHARD (a multi-GPU rank, tile_row_step > 1): most gaussians leave at one of the cull tests and the kernel is bound by
-    // latency, not bytes — every geometry load is issued up here, before the first exit, instead of one memory round trip per
-    // test (G = 8: 0.524 -> 0.506 ms per shard).  A whole frame is HBM-bound and keeps the loads behind the z cull: hoisted they
-    // cost 32 B per culled gaussian.
-    float ls[3];
-    float4 q;
-    float op_logit;
-    if (SHARD) {
-        ls[0] = sc.log_scales[3 * i]; ls[1] = sc.log_scales[3 * i + 1]; ls[2] = sc.log_scales[3 * i + 2];
-        q = reinterpret_cast<const float4 *>(sc.quats)[i];
-        op_logit = sc.opacity_logit[i];
-    }
+    g.p[0] = p[0]; g.p[1] = p[1]; g.p[2] = p[2];
     const float *V = cam.V, *F = cam.F;
     // project_to_camera_space, rasterize.py:80-86
     float cm[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) cm[j] = ((p[0] * V[0 + j] + p[1] * V[4 + j]) + p[2] * V[8 + j]) + V[12 + j];
     const bool culled = cm[2] < GSR_CULL_Z;  // :377
-    if (!DEBUG && culled) { depth_key[i] = KEY_INVALID; return; }
+    if (!DEBUG && culled) return g;
 
     // clip-space point, :374, cull zeroing :378, perspective divide :381-382
     float pt[4];
@@ -71,37 +76,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
     const float Wf = (float)cam.W, Hf = (float)cam.H;
     const float mx = ((ndc_x + 1.0f) * Wf - 1.0f) / 2.0f, my = ((ndc_y + 1.0f) * Hf - 1.0f) / 2.0f;
 
-    if (!SHARD) { ls[0] = sc.log_scales[3 * i]; ls[1] = sc.log_scales[3 * i + 1]; ls[2] = sc.log_scales[3 * i + 2]; }
-    // ---- multi-GPU shard early-out (tile rows row_begin, row_begin + row_step, ...) ---------------------------
-    // Before the quaternion load and the covariance math: a bound on the reference's radius (:179-181) from the
-    // largest scale alone.  cov2D = T Sigma T^T + 0.3 I with T = J A (:224-232), so its trace is at most
-    // |A|^2 smax^2 (|J_0|^2 + |J_1|^2) + 0.6, its largest eigenvalue at most ~the trace (det >= 0 up to rounding; the
-    // 0.1 floor of :172 adds < 0.32), and the radius at most 3 sqrt(.) + 1 (ceil).  Padded by 2 % + 1.5 px against
-    // fp32 rounding.  The final tile rows are a subset of the reference rect's rows, which are a subset of
-    // [floor((my - Rb) / 16), floor((my + Rb + 15) / 16)]; if no row of this rank lies in there the gaussian cannot
-    // reach it.  Anything non-finite falls through to the full path.  (Property-tested against row_step = 1:
-    // shards reassemble bit-exactly.)
-    if (!DEBUG && SHARD && !keep_ref_drawn) {
-        const float iz = 1.0f / cm[2];
-        const float u = fminf(cam.limx, fmaxf(-cam.limx, cm[0] * iz)), v = fminf(cam.limy, fmaxf(-cam.limy, cm[1] * iz));
-        const float jx = cam.fx * iz, jy = cam.fy * iz;
-        const float smax = expf(2.0f * fmaxf(ls[0], fmaxf(ls[1], ls[2])));
-        const float trb = cam.w_sigma2 * smax * (jx * jx * (1.0f + u * u) + jy * jy * (1.0f + v * v)) + 0.6f;
-        const float Rb = 3.0f * sqrtf(1.02f * trb + 0.4f) + 1.5f;
-        if (Rb < 1.0e8f && fabsf(my) < 1.0e8f) {
-            const int lo = max((int)floorf((my - Rb) * 0.0625f), 0), hi = (int)floorf((my + Rb + 15.0f) * 0.0625f);
-            int r = (lo - row_begin) % row_step;
-            if (r < 0) r += row_step;
-            const int first = r == 0 ? lo : lo + (row_step - r);
-            if (first > hi) { depth_key[i] = KEY_INVALID; return; }
-        }
-    }
-
     // cov3D, :357
-    if (!SHARD) {
-        q = reinterpret_cast<const float4 *>(sc.quats)[i];
-        op_logit = sc.opacity_logit[i];
-    }
+    const float ls[3] = {sc.log_scales[3 * i], sc.log_scales[3 * i + 1], sc.log_scales[3 * i + 2]};
+    const float4 q = reinterpret_cast<const float4 *>(sc.quats)[i];
+    const float op_logit = sc.opacity_logit[i];
     float C3[3][3];
     cov3d_of(ls, q, C3);
 
@@ -196,20 +174,54 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
         }
     }
 
+    g.visible = visible;
+    g.keep_empty = !visible && keep_ref_drawn && ref_drawn;
+    g.key = __float_as_uint(cm[2]);  // z >= 0.2 > 0: IEEE bits are monotone in z (rasterize.py:424-425)
+    g.tx0 = tx0; g.ty0 = ty0; g.tx1 = tx1; g.ty1 = ty1;
+    g.mx = mx; g.my = my; g.sx = sx; g.sy = sy; g.sxy = sxy; g.pthr = pthr; g.op = op;
+    return g;
+}
+
+// Colour of gaussian `i` seen from the camera: sh_to_rgb, spherical_harmonics.py:27-73 (rasterize.py:368).
+template <bool SH16>
+__device__ __forceinline__ void colour_one(const GsrScene &sc, const Cam &cam, int64_t i, const float p[3], float rgb[3])
+{
+    float sh[48];
+    if (SH16) load_sh48_f16(sc.sh, i, sh);
+    else load_sh48(reinterpret_cast<const float *>(sc.sh), i, sh);
+    sh_eval(p, sh, cam.cc, sc.sh_degree, rgb);
+}
+
+__device__ __forceinline__ uint32_t pack_rect8(const GeoOut &g)
+{
+    return (uint32_t)(g.tx0 & 255) | ((uint32_t)(g.ty0 & 255) << 8) | ((uint32_t)((g.tx1 - 1) & 255) << 16) | ((uint32_t)((g.ty1 - 1) & 255) << 24);
+}
+
+// Whole frame: one thread per gaussian.
+template <bool DEBUG, bool SH16>
+__global__ __launch_bounds__(256, (SH16 && !DEBUG) ? 8 : 4) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, GaussRec *__restrict__ rec,
+                                                         ushort4 *__restrict__ rect, uint32_t *__restrict__ rect8, uint32_t *__restrict__ depth_key,
+                                                         GsrDebugOut dbg,
+                                                         uint32_t *__restrict__ ctrl_words, int ctrl_reset_words, int packed_rect)
+{
+    // frame reset: nothing in this kernel reads FrameCtrl and every later kernel of the frame is stream-ordered behind it,
+    // so workgroup 0 clears the counters here (a hipMemsetAsync costs two blit kernels and a dispatch bubble, ~20 us)
+    if (blockIdx.x == 0)
+        for (int w = threadIdx.x; w < ctrl_reset_words; w += 256) ctrl_words[w] = 0u;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // the literal, not blockDim.x: that would pull in the hidden kernarg block
+    if (i >= sc.n) return;
+    // (the gaussian id is not written: pass 0 of the depth sort synthesises the identity payload, 8 B per gaussian less traffic)
+    const GeoOut g = geometry_one<DEBUG>(sc, cam, compat, no_cull, row_begin, row_step, keep_ref_drawn, dbg, i);
     float rgb[3] = {0.f, 0.f, 0.f};
-    if (visible || (DEBUG && dbg.rgb)) {
-        float sh[48];
-        if (SH16) load_sh48_f16(sc.sh, i, sh);
-        else load_sh48(reinterpret_cast<const float *>(sc.sh), i, sh);
-        sh_eval(p, sh, cam.cc, sc.sh_degree, rgb);  // :368
+    if (g.visible || (DEBUG && dbg.rgb)) {
+        colour_one<SH16>(sc, cam, i, g.p, rgb);
         if (DEBUG && dbg.rgb) { dbg.rgb[3 * i] = rgb[0]; dbg.rgb[3 * i + 1] = rgb[1]; dbg.rgb[3 * i + 2] = rgb[2]; }
     }
-
-    if (!visible) {
+    if (!g.visible) {
         // progressive render (draw_limit): the depth rank must count every gaussian the reference draws, also those
         // that cannot touch a pixel here; they stay in the sort with an empty tile rect
-        if (keep_ref_drawn && ref_drawn) {
-            depth_key[i] = __float_as_uint(cm[2]);
+        if (g.keep_empty) {
+            depth_key[i] = g.key;
             // only the form the binning will read is written: packed bytes ride through the depth sort as its second
             // payload when the frame has at most 256 x 256 tiles, otherwise the rect is gathered by gaussian id
             if (packed_rect) rect8[i] = 1u;  // packed {x0 = 1, y0 = 0, x1 - 1 = 0, y1 - 1 = 0}: zero width, i.e. no tiles
@@ -219,18 +231,187 @@ __global__ __launch_bounds__(256) void preprocess_kernel(GsrScene sc, Cam cam, i
         }
         return;
     }
-    depth_key[i] = __float_as_uint(cm[2]);  // z >= 0.2 > 0: IEEE bits are monotone in z (rasterize.py:424-425)
-    if (packed_rect) rect8[i] = (uint32_t)(tx0 & 255) | ((uint32_t)(ty0 & 255) << 8) | ((uint32_t)((tx1 - 1) & 255) << 16) | ((uint32_t)((ty1 - 1) & 255) << 24);
-    else rect[i] = make_ushort4((unsigned short)tx0, (unsigned short)ty0, (unsigned short)tx1, (unsigned short)ty1);
-    const float LOG2E = 1.4426950408889634f;
+    depth_key[i] = g.key;
+    if (packed_rect) rect8[i] = pack_rect8(g);
+    else rect[i] = make_ushort4((unsigned short)g.tx0, (unsigned short)g.ty0, (unsigned short)g.tx1, (unsigned short)g.ty1);
     GaussRec r;
-    const float A = (-0.5f * sx) * LOG2E, B = (-sxy) * LOG2E, C = (-0.5f * sy) * LOG2E;
-    // -B/(2C), -B/(2A): only used by the culling test, and only when the conic is positive definite (A, C < 0)
-    const float rc = pthr < -1e37f ? 0.0f : -0.5f * B / C, ra = pthr < -1e37f ? 0.0f : -0.5f * B / A;
-    r.q0 = make_float4(mx, my, rc, ra);
-    r.q1 = make_float4(A, B, C, pthr);
-    r.q2 = make_float4(log2f(op), rgb[0], rgb[1], rgb[2]);
+    float log2_op;
+    record_of(g, &r.q0, &r.q1, &log2_op);
+    r.q2 = make_float4(log2_op, rgb[0], rgb[1], rgb[2]);
     rec[i] = r;
+}
+
+// ---- multi-GPU shard (tile rows row_begin, row_begin + row_step, ...) ---------------------------------------------------
+// A rank of G keeps ~1/G of the gaussians, but which ones depends on the camera, so every rank has to look at all N.  Run
+// through the kernel above, nearly every wave still holds a few survivors and walks the whole path with most lanes idle
+// (G = 8: 41 % of the lanes pass a cheap bound, 13 % are visible), and pass 0 of the depth sort then scans N keys to drop
+// 7 of 8.  shard_preprocess_kernel instead works in three phases per workgroup of SHARD_SPAN consecutive gaussians, each in
+// dense waves, handing the survivors on through id-ordered lists in LDS:
+//   1. bound   24 B per gaussian (mean, log-scales): which rows can the reference's rect reach at most?
+//   2. geometry of the candidates (exact: the rows of the refined rect)
+//   3. colour of the visible ones (the 192-B SH read), then the workgroup's (key, id, packed rect) records go out as one
+//      contiguous run; shard_compact_kernel closes the gaps between the workgroups' runs, so the depth sort starts on the
+//      V_rank visible records instead of N keys, and stays stable by id.  (Letting pass 0 of the sort read the runs in
+//      place measured slower than this copy: 18 + 44 us against 17 + 6 + 18.)
+// Every geometry array is read once and the SH rows of the visible gaussians once.
+// The bound (reference radius, rasterize.py:179-181, from the largest scale alone): cov2D = T Sigma T^T + 0.3 I with
+// T = J A (:224-232), so its trace is at most |A|^2 smax^2 (|J_0|^2 + |J_1|^2) + 0.6, its largest eigenvalue at most ~the
+// trace (det >= 0 up to rounding; the 0.1 floor of :172 adds < 0.32), and the radius at most 3 sqrt(.) + 1 (ceil).  Padded
+// by 2 % + 1.5 px against fp32 rounding.  The final tile rows are a subset of the reference rect's rows, which are a subset
+// of [floor((my - Rb) / 16), floor((my + Rb + 15) / 16)]; if no row of this rank lies in there the gaussian cannot reach
+// it.  Anything non-finite stays a candidate.  (Property-tested against row_step = 1: shards reassemble bit-exactly.)
+constexpr int SHARD_PER = 4, SHARD_SPAN = 256 * SHARD_PER;  // gaussians per thread / per workgroup in phase 1
+
+// Stable append of the flagged threads' items to an LDS list, in thread order.  Returns this thread's position (valid when
+// `flag`); *count advances by the number of flagged threads.  Two barriers.
+__device__ __forceinline__ uint32_t block_append_256(bool flag, uint32_t *s_wave /* [4] */, uint32_t *count /* LDS */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t pos = *count + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t c = s_wave[w];
+        if (w < wave) pos += c;
+        tot += c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *count += tot;
+    return pos;
+}
+
+template <bool SH16>
+__global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step,
+                                                               GaussRec *__restrict__ rec, ushort4 *__restrict__ rect,
+                                                               uint32_t *__restrict__ run_key, uint32_t *__restrict__ run_id,
+                                                               uint32_t *__restrict__ run_rect8, uint32_t *__restrict__ run_cnt,
+                                                               uint32_t *__restrict__ ctrl_words, int ctrl_reset_words, int packed_rect)
+{
+    __shared__ uint32_t s_cand[SHARD_SPAN];
+    __shared__ uint32_t s_id[SHARD_SPAN], s_key[SHARD_SPAN], s_rect8[SHARD_SPAN];
+    __shared__ float s_l2op[SHARD_SPAN];
+    __shared__ uint32_t s_wave[4], s_ncand, s_nvis;
+    if (blockIdx.x == 0)  // frame reset, as in preprocess_kernel
+        for (int w = threadIdx.x; w < ctrl_reset_words; w += 256) ctrl_words[w] = 0u;
+    if (threadIdx.x == 0) { s_ncand = 0; s_nvis = 0; }
+    const int64_t base = (int64_t)blockIdx.x * SHARD_SPAN;
+    const float *V = cam.V, *F = cam.F;
+    const float Hf = (float)cam.H;
+
+    // ---- phase 1: the bound.  id = base + r * 256 + thread, appended round by round: the list is in id order ----
+    float p[SHARD_PER][3], ls[SHARD_PER];
+#pragma unroll
+    for (int r = 0; r < SHARD_PER; ++r) {
+        const int64_t i = base + r * 256 + threadIdx.x;
+        const bool in = i < sc.n;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) p[r][j] = in ? sc.means[3 * i + j] : 0.0f;
+        ls[r] = in ? fmaxf(sc.log_scales[3 * i], fmaxf(sc.log_scales[3 * i + 1], sc.log_scales[3 * i + 2])) : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SHARD_PER; ++r) {
+        const int64_t i = base + r * 256 + threadIdx.x;
+        // the same expressions as geometry_one (this file is built with -ffp-contract=off)
+        float cm[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cm[j] = ((p[r][0] * V[0 + j] + p[r][1] * V[4 + j]) + p[r][2] * V[8 + j]) + V[12 + j];
+        bool k = i < sc.n && !(cm[2] < GSR_CULL_Z);
+        const float pt1 = ((p[r][0] * F[1] + p[r][1] * F[5]) + p[r][2] * F[9]) + F[13];
+        const float pt3 = ((p[r][0] * F[3] + p[r][1] * F[7]) + p[r][2] * F[11]) + F[15];
+        const float p_w = 1.0f / (pt3 + 0.0000001f);
+        const float ndc_y = pt1 * p_w;
+        const float my = ((ndc_y + 1.0f) * Hf - 1.0f) / 2.0f;
+        const float iz = 1.0f / cm[2];
+        const float u = fminf(cam.limx, fmaxf(-cam.limx, cm[0] * iz)), v = fminf(cam.limy, fmaxf(-cam.limy, cm[1] * iz));
+        const float jx = cam.fx * iz, jy = cam.fy * iz;
+        const float smax = expf(2.0f * ls[r]);
+        const float trb = cam.w_sigma2 * smax * (jx * jx * (1.0f + u * u) + jy * jy * (1.0f + v * v)) + 0.6f;
+        const float Rb = 3.0f * sqrtf(1.02f * trb + 0.4f) + 1.5f;
+        if (k && Rb < 1.0e8f && fabsf(my) < 1.0e8f) {
+            const int lo = max((int)floorf((my - Rb) * 0.0625f), 0), hi = (int)floorf((my + Rb + 15.0f) * 0.0625f);
+            int rr = (lo - row_begin) % row_step;
+            if (rr < 0) rr += row_step;
+            const int first = rr == 0 ? lo : lo + (row_step - rr);
+            if (first > hi) k = false;
+        }
+        const uint32_t pos = block_append_256(k, s_wave, &s_ncand);
+        if (k) s_cand[pos] = (uint32_t)i;
+    }
+    __syncthreads();
+
+    // ---- phase 2: geometry of the candidates, 256 at a time; the visible ones are appended in order ----
+    const uint32_t ncand = s_ncand;
+    const GsrDebugOut none = {};
+    for (uint32_t c0 = 0; c0 < ncand; c0 += 256) {
+        const uint32_t j = c0 + threadIdx.x;
+        GeoOut g;
+        g.visible = false;
+        int64_t i = 0;
+        if (j < ncand) {
+            i = (int64_t)s_cand[j];
+            g = geometry_one<false>(sc, cam, compat, no_cull, row_begin, row_step, 0, none, i);
+        }
+        const uint32_t pos = block_append_256(g.visible, s_wave, &s_nvis);
+        if (g.visible) {
+            s_id[pos] = (uint32_t)i;
+            s_key[pos] = g.key;
+            s_rect8[pos] = pack_rect8(g);
+            float4 q0, q1;
+            float log2_op;
+            record_of(g, &q0, &q1, &log2_op);
+            s_l2op[pos] = log2_op;
+            rec[i].q0 = q0;
+            rec[i].q1 = q1;
+            if (!packed_rect) rect[i] = make_ushort4((unsigned short)g.tx0, (unsigned short)g.ty0, (unsigned short)g.tx1, (unsigned short)g.ty1);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: colour of the visible ones; the workgroup's run of sort records ----
+    const uint32_t nvis = s_nvis;
+    if (threadIdx.x == 0) run_cnt[blockIdx.x] = nvis;
+    for (uint32_t j = threadIdx.x; j < nvis; j += 256) {
+        const int64_t i = (int64_t)s_id[j];
+        const float pm[3] = {sc.means[3 * i], sc.means[3 * i + 1], sc.means[3 * i + 2]};
+        float rgb[3];
+        colour_one<SH16>(sc, cam, i, pm, rgb);
+        rec[i].q2 = make_float4(s_l2op[j], rgb[0], rgb[1], rgb[2]);
+        run_key[base + j] = s_key[j];
+        run_id[base + j] = (uint32_t)i;
+        if (packed_rect) run_rect8[base + j] = s_rect8[j];
+    }
+}
+
+// Workgroup b moves the run of shard_preprocess workgroup b to its place in the compact arrays: position = records of the
+// workgroups before it (the counts are a few KB, L2-resident, summed here four at a time: cheaper than a scan kernel and
+// its boundary) + rank inside.
+__global__ __launch_bounds__(256) void shard_compact_kernel(const uint32_t *__restrict__ run_key, const uint32_t *__restrict__ run_id,
+                                                            const uint32_t *__restrict__ run_rect8, const uint32_t *__restrict__ run_cnt,
+                                                            uint32_t *__restrict__ key, uint32_t *__restrict__ id, uint32_t *__restrict__ rect8,
+                                                            uint32_t *__restrict__ n_records, int packed_rect)
+{
+    __shared__ uint32_t scratch[8];
+    const int b = (int)blockIdx.x, quads = b >> 2;
+    uint32_t mine = 0;
+    for (int q = threadIdx.x; q < quads; q += 256) {
+        const uint4 c = reinterpret_cast<const uint4 *>(run_cnt)[q];
+        mine += (c.x + c.y) + (c.z + c.w);
+    }
+    if ((int)threadIdx.x < (b & 3)) mine += run_cnt[4 * quads + threadIdx.x];
+    uint32_t before;
+    block_excl_scan_256(mine, scratch, &before);
+    const uint32_t cnt = run_cnt[b];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_records = before + cnt;
+    const size_t src = (size_t)b * SHARD_SPAN;
+    for (uint32_t j = threadIdx.x; j < cnt; j += 256) {
+        key[before + j] = run_key[src + j];
+        id[before + j] = run_id[src + j];
+        if (packed_rect) rect8[before + j] = run_rect8[src + j];
+    }
 }
 
 static Cam make_cam(const GsrCamera &c)
@@ -274,17 +455,32 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
     GsrDebugOut d;
     memset(&d, 0, sizeof d);
     if (dbg) d = *dbg;
-#define GSR_LAUNCH_PRE2(DBG, H16, SHD)                                                                                       \
-    hipLaunchKernelGGL((preprocess_kernel<DBG, H16, SHD>), dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat,       \
-                       opts.no_footprint_cull, opts.tile_row_begin, opts.tile_row_step < 1 ? 1 : opts.tile_row_step,          \
-                       opts.draw_limit > 0 ? 1 : 0, ws.rec, ws.rect, ws.rect8[0], ws.key[0], d,                             \
-                       reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, rect_fits_8bit(ws) ? 1 : 0)
-#define GSR_LAUNCH_PRE(DBG, H16) do { if (opts.tile_row_step > 1) GSR_LAUNCH_PRE2(DBG, H16, true); else GSR_LAUNCH_PRE2(DBG, H16, false); } while (0)
+    const int row_step = opts.tile_row_step < 1 ? 1 : opts.tile_row_step, packed = rect_fits_8bit(ws) ? 1 : 0;
     const bool h16 = scene.sh_dtype == 1;
+#define GSR_LAUNCH_PRE(DBG, H16)                                                                                              \
+    hipLaunchKernelGGL((preprocess_kernel<DBG, H16>), dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat,             \
+                       opts.no_footprint_cull, opts.tile_row_begin, row_step, opts.draw_limit > 0 ? 1 : 0, ws.rec, ws.rect,     \
+                       ws.rect8[0], ws.key[0], d, reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, packed)
+    // debug outputs cover every gaussian: for a shard (below) that is a pass of its own, whose other outputs are then
+    // overwritten
     if (dbg) { if (h16) GSR_LAUNCH_PRE(true, true); else GSR_LAUNCH_PRE(true, false); }
-    else     { if (h16) GSR_LAUNCH_PRE(false, true); else GSR_LAUNCH_PRE(false, false); }
+    if (shard_compact(opts)) {
+        const unsigned sgrid = (unsigned)((scene.n + SHARD_SPAN - 1) / SHARD_SPAN);
+        // the workgroups' runs go to the "out" halves of the depth sort's ping-pong buffers, idle until its pass 0 scatters
+        // into them (after shard_compact_kernel has read them); their lengths to blk_sum, idle until the pair count
+        uint32_t *run_cnt = ws.blk_sum;
+#define GSR_LAUNCH_SHARD(H16)                                                                                                 \
+    hipLaunchKernelGGL(shard_preprocess_kernel<H16>, dim3(sgrid), dim3(256), 0, s, scene, k, opts.reference_compat,             \
+                       opts.no_footprint_cull, opts.tile_row_begin, row_step, ws.rec, ws.rect, ws.key[1], ws.val[1], ws.rect8[1], \
+                       run_cnt, reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, packed)
+        if (h16) GSR_LAUNCH_SHARD(true); else GSR_LAUNCH_SHARD(false);
+#undef GSR_LAUNCH_SHARD
+        hipLaunchKernelGGL(shard_compact_kernel, dim3(sgrid), dim3(256), 0, s, ws.key[1], ws.val[1], ws.rect8[1], run_cnt, ws.key[0], ws.val[0],
+                           ws.rect8[0], &ws.ctrl->n_records, packed);
+    } else if (!dbg) {
+        if (h16) GSR_LAUNCH_PRE(false, true); else GSR_LAUNCH_PRE(false, false);
+    }
 #undef GSR_LAUNCH_PRE
-#undef GSR_LAUNCH_PRE2
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

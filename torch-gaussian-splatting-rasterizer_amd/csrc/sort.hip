@@ -231,23 +231,25 @@ static void launch_pass(const uint32_t *kin, const uint32_t *vin, const uint32_t
 
 // Depth order of the gaussians (rasterize.py:424-425).  Always four passes enqueued, 3 run on ordinary scenes (header).
 // Afterwards FrameCtrl.n_visible = V and the sorted ids / packed rects are in val[p] / rect8[p], p = sort_passes & 1.
-int launch_depth_sort(const Workspace &ws, bool packed_rect, hipStream_t s)
+int launch_depth_sort(const Workspace &ws, bool packed_rect, bool compact_input, hipStream_t s)
 {
     if (ws.n <= 0) return GSR_OK;
     constexpr int TILE = DEPTH_SORT_THREADS * DEPTH_SORT_ITEMS;
     const int nblk = (int)((ws.n + TILE - 1) / TILE);
     if (nblk > ws.hist_blocks) { set_error("radix sort: %d tiles exceed the histogram stride %d", nblk, ws.hist_blocks); return GSR_ERR_WORKSPACE; }
-    const uint32_t *cnt_dev = nullptr;
+    // compact_input (multi-GPU shard): the input is FrameCtrl.n_records (key, id[, rect]) records in id order, left in
+    // key[0] / val[0] / rect8[0] by preprocess.hip, instead of one key per gaussian
+    const uint32_t *cnt_dev = compact_input ? &ws.ctrl->n_records : nullptr;
     for (int p = 0; p < 4; ++p) {
         const PassSpec ps = {0, 0u, DEPTH_KEY_BASE, KEY_INVALID, p};
         const int in = p & 1, out = in ^ 1;
         const bool first = p == 0;
         if (packed_rect)
             launch_pass<DEPTH_SORT_THREADS, DEPTH_SORT_ITEMS, true>(ws.key[in], ws.val[in], ws.rect8[in], ws.key[out], ws.val[out], ws.rect8[out], cnt_dev, ws.n, ps,
-                                                     first, first, first ? &ws.ctrl->n_visible : nullptr, ws, s);
+                                                     first, first && !compact_input, first ? &ws.ctrl->n_visible : nullptr, ws, s);
         else
             launch_pass<DEPTH_SORT_THREADS, DEPTH_SORT_ITEMS, false>(ws.key[in], ws.val[in], nullptr, ws.key[out], ws.val[out], nullptr, cnt_dev, ws.n, ps,
-                                                      first, first, first ? &ws.ctrl->n_visible : nullptr, ws, s);
+                                                      first, first && !compact_input, first ? &ws.ctrl->n_visible : nullptr, ws, s);
         cnt_dev = &ws.ctrl->n_visible;  // later passes only see the survivors
     }
     GSR_HIP(hipGetLastError());
