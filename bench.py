@@ -8,7 +8,10 @@ metric is quoted on (mip360_like(6_131_954, seed 361), ring ca
 arithmetic: fp32 coefficients, fp32 frame, reference_compat, every gaussian blended (no approximate early termination):
 preprocess -> depth sort -> tile binning -> blend, scene resident in HBM before the timed region.  With N > 1 the SAME
 frame is sharded by interleaved tile rows over the N GPUs and gathered to rank 0 over RCCL (strong scaling: total work
-per frame fixed).
+per frame fixed).  `value` is throughput: --frames-in-flight independent frames (default 4) are in flight per GPU, each on
+its own HIP stream with its own workspace (renderer.FramesInFlight), every frame complete and bit-identical to
+single-stream rendering; `single_stream` carries the same loop with one frame in flight (the per-frame latency), and the
+per-stage times / roofline are measured on one stream.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      HBM roofline of the dominant kernel (blend): algorithmic bytes 40*E + 12*P + 8*tiles per launch / its
@@ -77,6 +80,9 @@ def parse():
     ap.add_argument("--input_dir", default="", help="real data: MipNeRF-360 scene dir with sparse/0/{images,cameras}.bin")
     ap.add_argument("--trained_model_path", default="", help="real data: INRIA model dir (point_cloud/iteration_30000/point_cloud.ply)")
     ap.add_argument("--legs", default="configs2,early_out,garden", help="extra legs at N=1 (comma list; '' = none)")
+    ap.add_argument("--frames-in-flight", type=int, default=4,
+                    help="independent frames in flight per GPU, each on its own HIP stream and workspace (1 = one stream; the "
+                         "single-stream figure is reported beside the headline either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
@@ -121,14 +127,20 @@ def build_workload(name, args, n_override=0):
     return cols, cam_list, n, W, H, desc
 
 
-def timed_frames(R, cams, opts, out, steps, warmup, dev):
-    """Single-GPU legs: `warmup` untimed frames, then `steps` frames between two device synchronisations."""
+def timed_frames(R, cams, opts, out, steps, warmup, dev, slots=1):
+    """Single-GPU legs: `warmup` untimed frames, then `steps` frames between two device synchronisations, `slots` frames in
+    flight like the headline loop (slot 0 is `R` and `out`; the other slots get their own workspace and frame buffer)."""
+    from gsr_amd import renderer
+
+    fif = renderer.FramesInFlight(R.scene, slots=slots, max_pairs=R.max_pairs)
+    fif.rasterizers[0] = R
+    outs = [out] + [torch.empty_like(out) for _ in range(slots - 1)]
     for i in range(warmup):
-        R.enqueue(cams[i % len(cams)], opts, out=out)
+        fif.submit(cams[i % len(cams)], opts, out=outs[i % slots], slot=i % slots)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(steps):
-        R.enqueue(cams[i % len(cams)], opts, out=out)
+        fif.submit(cams[i % len(cams)], opts, out=outs[i % slots], slot=i % slots)
     torch.cuda.synchronize(dev)
     return time.perf_counter() - t0
 
@@ -188,67 +200,101 @@ def main():
     ncam = len(cams)
     plan = gdist.TileRowPlan(H, W, world)
     out_dtype = torch.bfloat16 if args.bf16_output else torch.float32
-    fg = gdist.FrameGather(plan, rank, dev, dtype=out_dtype)
-    R = renderer.Rasterizer(scene)
-    state1 = {"i": 0}
-    if world == 1:  # no sharding: blend straight into the frame
+    S = max(1, args.frames_in_flight)
+    fif = renderer.FramesInFlight(scene, slots=S)
+    R = fif.rasterizers[0]
+    state = {"i": 0}
+    if world == 1:  # no sharding: blend straight into a frame buffer per slot
         opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl, output_bf16=args.bf16_output)
-        strip_view = fg.frame
+        frames = [torch.zeros((H, W, 3), dtype=out_dtype, device=dev) for _ in range(S)]
+        strip_view = frames[0]
 
         def step():
-            c = cams[state1["i"] % ncam]
-            state1["i"] += 1
-            return R.enqueue(c, opts, out=strip_view)
+            f = state["i"]
+            state["i"] += 1
+            fif.submit(cams[f % ncam], opts, out=frames[f % S], slot=f % S)
+            return frames[f % S]
+
+        def drain():
+            return None
     else:
         opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl, output_bf16=args.bf16_output,
                                      **plan.shard_options(rank))
-        strip_view = fg.own_view(0)
-        state = {"i": 0, "pending": None}
+        # gdist.ShardedFrames: frame f renders on stream f % S into wire buffer f % S, its strip is gathered asynchronously
+        # over RCCL while the next frames render, frames are finished in order on the main stream
+        sf = gdist.ShardedFrames(plan, rank, dev, S, lambda k, c, strip: fif.rasterizers[k].enqueue(c, opts, out=strip),
+                                 dtype=out_dtype, streams=fif.streams)
+        strip_view = sf.fg.own_view(0)
 
         def step():
-            # frame k's strip is gathered asynchronously (RCCL stream) while frame k+1 renders into the other buffer
-            buf = state["i"] & 1
-            c = cams[state["i"] % ncam]
+            f = state["i"]
             state["i"] += 1
-            R.enqueue(c, opts, out=fg.own_view(buf))
-            h = fg.gather_async(buf)
-            done = fg.finish(state["pending"]) if state["pending"] is not None else None
-            state["pending"] = h
-            return done
+            return sf.submit(cams[f % ncam])
 
         def drain():
-            out = fg.finish(state["pending"]) if state["pending"] is not None else None
-            state["pending"] = None
-            return out
+            return sf.drain()
 
     # size the pair buffer to the heaviest view once (grows on overflow), outside the timed region
     need = max(R.fit_pairs(c, opts) for c in cams)
-    R.max_pairs = need
+    fif.set_max_pairs(need)
     R.render(cam, opts, out=strip_view)
     shard_stats = dict(R.last_stats)
-    for _ in range(args.warmup):
-        step()
-    state1["i"] = 0
-    if world > 1:
-        drain()
+    torch.cuda.synchronize(dev)
+
+    def timed_region(step_fn, drain_fn, steps, warmup):
+        for _ in range(warmup):
+            step_fn()
+        drain_fn()
         state["i"] = 0
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame = step()
-    if world > 1:
-        frame = drain()  # the last frame's gather completes inside the timed region
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    R.stats()  # raises if the last frame overflowed
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        last = None
+        for _ in range(steps):
+            last = step_fn()
+        if world > 1:
+            last = drain_fn()  # the last frames' gathers complete inside the timed region
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, last
+
+    elapsed, frame = timed_region(step, drain, args.steps, args.warmup)
+    for k in range(S):
+        if fif.rasterizers[k]._ws is not None:
+            fif.stats(k)  # raises if the slot's last frame overflowed
+    # the same loop with ONE frame in flight (one stream, one workspace): the per-frame latency figure
+    single = None
+    if S > 1:
+        one = renderer.FramesInFlight(scene, slots=1, max_pairs=need)
+        st1 = {"i": 0}
+        sf1 = None
+        if world > 1:
+            sf1 = gdist.ShardedFrames(plan, rank, dev, 1, lambda k, c, strip: one.rasterizers[0].enqueue(c, opts, out=strip),
+                                      dtype=out_dtype, streams=one.streams)
+
+        def step1():
+            f = st1["i"]
+            st1["i"] += 1
+            if world == 1:
+                one.submit(cams[f % ncam], opts, out=frames[0], slot=0)
+                return None
+            return sf1.submit(cams[f % ncam])
+
+        def drain1():
+            st1["i"] = 0
+            return sf1.drain() if sf1 is not None else None
+
+        el1, _ = timed_region(step1, drain1, args.steps, args.warmup)
+        single = {"frames_per_s": args.steps / el1, "ms_per_frame": 1e3 * el1 / args.steps,
+                  "note": "the same timed loop with one frame in flight (one stream, one workspace): per-frame latency"}
+        del one, sf1
 
     result = None
     if rank == 0:
@@ -267,6 +313,9 @@ def main():
                        "blend_impl": {0: "valu", 1: "valu, plain-C walk", 2: "mfma (experimental)"}.get(args.blend_impl, str(args.blend_impl))},
             "stats_rank0_shard": shard_stats,
         }
+        result["config"]["frames_in_flight"] = S
+        if single is not None:
+            result["single_stream"] = single
 
     # ---- rank 0: per-stage timing + roofline of ITS shard (the whole frame at N=1), outside the timed region; at N=1 also
     # ---- PSNR vs the oracle, the extra legs and the CPU baseline -------------------------------------------------------
@@ -344,7 +393,7 @@ def main():
         # inside its PSNR >= 50 dB tolerance
         if "early_out" in legs and args.early_out_T == 0.0:
             eo_opts = renderer.make_options(early_out_T=1e-4, blend_impl=args.blend_impl)
-            el = timed_frames(R, cams, eo_opts, leg_out, steps_leg, warm_leg, dev)
+            el = timed_frames(R, cams, eo_opts, leg_out, steps_leg, warm_leg, dev, S)
             R.enqueue(cam, eo_opts, out=leg_out)
             s = R.stats()
             leg_imgs["early_out"] = leg_out.cpu().numpy()
@@ -359,7 +408,7 @@ def main():
             Rh = renderer.Rasterizer(scene_h, max_pairs=R.max_pairs)
             h_opts = renderer.make_options(output_bf16=True)
             h_out = torch.empty((H, W, 3), dtype=torch.bfloat16, device=dev)
-            el = timed_frames(Rh, cams, h_opts, h_out, steps_leg, warm_leg, dev)
+            el = timed_frames(Rh, cams, h_opts, h_out, steps_leg, warm_leg, dev, S)
             Rh.enqueue(cam, h_opts, out=h_out)
             s = Rh.stats()
             leg_imgs["configs2"] = h_out.float().cpu().numpy()
@@ -418,7 +467,7 @@ def main():
             Rg = renderer.Rasterizer(gscene)
             g_opts = renderer.make_options()
             Rg.max_pairs = max(Rg.fit_pairs(c, g_opts) for c in gcams)
-            el = timed_frames(Rg, gcams, g_opts, leg_out, steps_leg, warm_leg, dev)
+            el = timed_frames(Rg, gcams, g_opts, leg_out, steps_leg, warm_leg, dev, S)
             Rg.enqueue(gcams[0], g_opts, out=leg_out)
             s = Rg.stats()
             result["garden"] = {"frames_per_s": steps_leg / el, "ms_per_step": 1e3 * el / steps_leg, "gaussians": gn,

@@ -51,6 +51,59 @@ def _worker(rank, world, port, H, W, q):
     q.put((rank, ok))
 
 
+def _pipeline_worker(rank, world, port, H, W, q):
+    """dist.ShardedFrames (bench.py's N-GPU loop) with 3 frames in flight over gloo: a fake render writes the rank's strip of
+    a known frame; 8 frames, so every wire buffer is reused; rank 0 must get every frame back, in order."""
+    import sys
+
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gsr_amd import dist as gdist
+
+    g = torch.Generator().manual_seed(99)
+    truth = [torch.rand((H, W, 3), generator=g) for _ in range(8)]
+    plan = gdist.TileRowPlan(H, W, world)
+
+    def render(slot, frame_index, strip):
+        strip.copy_(plan.split(truth[frame_index], rank)[: strip.shape[0]])
+
+    ok = True
+    for slots in (1, 3):
+        sf = gdist.ShardedFrames(plan, rank, "cpu", slots, render)
+        got = []
+        for i in range(len(truth)):
+            f = sf.submit(i)
+            if f is not None:
+                got.append(f.clone())
+        while sf.pending:
+            f = sf._finish_oldest()
+            if f is not None:
+                got.append(f.clone())
+        if rank == 0:
+            ok = ok and len(got) == len(truth) and all(torch.equal(a, b) for a, b in zip(got, truth))
+        else:
+            ok = ok and not got
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+@pytest.mark.parametrize("world,H,W", [(2, 93, 150), (3, 200, 64)])
+def test_frames_in_flight_pipeline_returns_every_frame_in_order(world, H, W):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, H, W, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(r, True) for r in range(world)]
+
+
 @pytest.mark.parametrize("world,H,W", [(2, 96, 160), (2, 93, 150), (3, 200, 64)])
 def test_gather_reassembles_the_frame(world, H, W):
     ctx = mp.get_context("spawn")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Multi-rank check of the tile-row sharding + framebuffer gather, launched under torch.distributed.run by
 tests/test_gpu_configs.py:  every rank renders its interleaved tile rows of the same scene for several frames in a row
-through the same step()/drain() schedule as bench.py (double-buffered asynchronous gather), rank 0 assembles each frame and
+through the same schedule as bench.py (gsr_amd.dist.ShardedFrames: several frames in flight, asynchronous gathers), rank 0 assembles each frame and
 compares it bit for bit with its own unsharded render.  Backend from GSR_BENCH_BACKEND: nccl (= RCCL, one rank per GPU) or
 gloo (ranks share the GPUs that exist; strips are staged through the host).  Prints DIST_CHECK_OK on success."""
 import os
@@ -33,25 +33,27 @@ def main():
     fx = synthetic.pinhole_focal(W)
     cams = [renderer.make_camera(p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H) for p in synthetic.ring_cameras(25)[:5]]
     plan = gdist.TileRowPlan(H, W, world)
-    fg = gdist.FrameGather(plan, rank, dev)
-    R = renderer.Rasterizer(scene)
+    slots = int(os.environ.get("GSR_DIST_CHECK_SLOTS", "3"))
+    fif = renderer.FramesInFlight(scene, slots=slots)
     opts = renderer.make_options(**plan.shard_options(rank))
-    R.max_pairs = max(R.fit_pairs(c, opts) for c in cams)
-
-    frames, pending = [], None
-    for i, c in enumerate(cams):  # bench.py's schedule: frame k's gather overlaps frame k+1's render into the other buffer
-        buf = i & 1
-        R.enqueue(c, opts, out=fg.own_view(buf))
-        h = fg.gather_async(buf)
-        if pending is not None:
-            f = fg.finish(pending)
-            if rank == 0:
-                frames.append(f.clone())
-        pending = h
-    f = fg.finish(pending)
-    if rank == 0:
-        frames.append(f.clone())
-    R.stats()
+    fif.set_max_pairs(max(fif.rasterizers[0].fit_pairs(c, opts) for c in cams))
+    torch.cuda.synchronize(dev)
+    # bench.py's schedule: `slots` frames in flight, each on its own stream / workspace / wire buffer, gathers asynchronous
+    sf = gdist.ShardedFrames(plan, rank, dev, slots, lambda k, c, strip: fif.rasterizers[k].enqueue(c, opts, out=strip),
+                             streams=fif.streams)
+    seq = cams + cams[:2]  # 7 frames: every buffer is reused at least once
+    frames = []
+    for c in seq:
+        f = sf.submit(c)
+        if rank == 0 and f is not None:
+            frames.append(f.clone())
+    while sf.pending:
+        f = sf._finish_oldest()
+        if rank == 0:
+            frames.append(f.clone())
+    for k in range(slots):
+        fif.stats(k)
+    cams = seq
     ok = True
     if rank == 0:
         full = renderer.Rasterizer(scene)

@@ -21,7 +21,7 @@ if shard:
     shape = plan.strip_shape(shard[1])
 else:
     opts, shape = renderer.make_options(), (H, W, 3)
-for S in (1, 2, 3, 4):
+for S in [int(x) for x in os.environ.get("GSR_OVERLAP_SLOTS", "1,2,3,4").split(",")]:
     Rs = [renderer.Rasterizer(scene) for _ in range(S)]
     streams = [torch.cuda.Stream() for _ in range(S)]
     outs = [torch.zeros(shape, device="cuda") for _ in range(S)]

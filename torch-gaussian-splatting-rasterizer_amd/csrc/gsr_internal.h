@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 #include "../../include/gsr.h"
 
@@ -124,7 +125,12 @@ inline bool rect_fits_8bit(const Workspace &ws) { return ws.tiles_x <= 256 && ws
 // A multi-GPU shard's preprocess (preprocess.hip) hands the depth sort a compact list of (key, id, rect) records of the rank's
 // visible gaussians instead of one key per gaussian.  Progressive frames (draw_limit) rank ALL gaussians the reference
 // draws, so they take the whole-frame path.
-inline bool shard_compact(const GsrOptions &o) { return o.tile_row_step > 1 && o.draw_limit == 0; }
+inline bool shard_compact(const GsrOptions &o)
+{
+    static const int forced = [] { const char *e = getenv("GSR_SHARD_PREPROCESS"); return e ? atoi(e) : -1; }();  // experiments: 0 / 1
+    if (o.tile_row_step <= 1 || o.draw_limit != 0) return false;
+    return forced >= 0 ? forced != 0 : o.tile_row_step >= 5;  // measured: 2 and 4 shards are as fast or faster through the whole-frame kernel
+}
 // Stage 2b: pairs of the depth-sorted gaussians -> per-tile depth-ordered lists + ranges[] (count, scan, emit, sort, ranges,
 // and with coarse binning the expansion).
 int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s);

@@ -11,7 +11,8 @@ bench.py); the strips themselves come from `Rasterizer.enqueue(..., output_layou
 """
 from __future__ import annotations
 
-from typing import List, Optional
+import contextlib
+from typing import Callable, List, Optional
 
 import torch
 import torch.distributed as dist
@@ -143,3 +144,59 @@ class FrameGather:
     def gather(self, buf: int = 0) -> Optional[torch.Tensor]:
         """Blocking form: every rank calls it after its strip is complete.  Rank 0 gets the frame."""
         return self.finish(self.gather_async(buf))
+
+
+class ShardedFrames:
+    """The N-GPU frame loop of one rank with `slots` frames in flight.
+
+    Frame f renders on stream f % slots into wire buffer f % slots (`render(slot, cam, strip)` enqueues this rank's strip
+    on the CURRENT stream — renderer.FramesInFlight's rasterizer of that slot); its strip is gathered asynchronously (RCCL
+    stream, ordered behind the render stream) while the next frames render.  Frames are finished in order on the caller's
+    stream, at most slots - 1 behind.  Before buffer f % slots is reused its render stream waits for the caller's stream,
+    which by then has waited for the previous gather out of that buffer and, on rank 0, has de-interleaved the receive
+    buffer that gather f will overwrite.  With streams = None (CPU tensors, or one stream) everything runs in program
+    order on the current stream; the schedule is the same.
+
+    submit() returns the frame finished by this call on rank 0 (a view of FrameGather.frame, overwritten by the next
+    finish) or None; drain() finishes what is still in flight and returns the last frame."""
+
+    def __init__(self, plan: TileRowPlan, rank: int, device, slots: int, render: Callable, dtype=torch.float32, group=None,
+                 streams=None):
+        if slots < 1:
+            raise ValueError("slots must be >= 1")
+        if streams is not None and len(streams) != slots:
+            raise ValueError("one stream per slot")
+        self.plan, self.rank, self.device, self.slots = plan, rank, device, int(slots)
+        self.fg = FrameGather(plan, rank, device, dtype=dtype, group=group, buffers=max(2, self.slots))
+        self.render, self.streams = render, streams
+        self.pending: List = []
+        self.frames_submitted = 0
+
+    def _finish_oldest(self):
+        _, h = self.pending.pop(0)
+        return self.fg.finish(h)
+
+    def submit(self, cam):
+        f = self.frames_submitted
+        self.frames_submitted += 1
+        k = f % self.slots
+        done = None
+        while self.pending and self.pending[0][0] <= f - self.slots:
+            done = self._finish_oldest()
+        if self.streams is not None:
+            st = self.streams[k]
+            st.wait_stream(torch.cuda.current_stream(self.device))
+            ctx = torch.cuda.stream(st)
+        else:
+            ctx = contextlib.nullcontext()
+        with ctx:
+            self.render(k, cam, self.fg.own_view(k))
+            h = self.fg.gather_async(k)
+        self.pending.append((f, h))
+        return done
+
+    def drain(self):
+        out = None
+        while self.pending:
+            out = self._finish_oldest()
+        return out

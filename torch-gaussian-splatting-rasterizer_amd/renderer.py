@@ -248,3 +248,53 @@ class Rasterizer:
                                  _stream_ptr(dev)))
         return out
 
+
+class FramesInFlight:
+    """Throughput mode for independent frames (a camera path, a batch of views): `slots` frames in flight, each on its own
+    HIP stream with its own workspace, so that one frame's HBM-bound stages (preprocess, sorts) overlap another's
+    VALU-bound blend and the short launch-bound kernels of a multi-GPU shard overlap each other.  libgsr keeps no state and
+    every call is stream-asynchronous, so this is plain use of the C ABI: one (workspace, stream) pair per slot.  Frames
+    are bit-identical to single-stream rendering; only the time per frame changes (tools/stream_overlap.py).
+
+    submit() returns the slot it used; the caller owns the ordering of its output buffers: wait(slot) makes the current
+    stream wait for that slot's last frame."""
+
+    def __init__(self, scene: GaussianScene, slots: int = 4, max_pairs: Optional[int] = None):
+        if slots < 1:
+            raise ValueError("slots must be >= 1")
+        self.scene = scene
+        self.rasterizers = [Rasterizer(scene, max_pairs=max_pairs) for _ in range(slots)]
+        self.streams = [torch.cuda.Stream(device=scene.device) for _ in range(slots)]
+        cur = torch.cuda.current_stream(scene.device)
+        for st in self.streams:  # the scene upload (and whatever else the caller enqueued) comes first
+            st.wait_stream(cur)
+        self._next = 0
+
+    @property
+    def slots(self) -> int:
+        return len(self.rasterizers)
+
+    def set_max_pairs(self, max_pairs: int) -> None:
+        for r in self.rasterizers:
+            r.max_pairs = int(max_pairs)
+
+    def submit(self, cam: GsrCamera, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None,
+               slot: Optional[int] = None) -> int:
+        """Enqueue one frame on the next slot's stream (round robin) and return the slot."""
+        k = self._next if slot is None else int(slot)
+        if slot is None:
+            self._next = (self._next + 1) % len(self.rasterizers)
+        with torch.cuda.stream(self.streams[k]):
+            self.rasterizers[k].enqueue(cam, opts, out=out)
+        return k
+
+    def wait(self, slot: int) -> None:
+        torch.cuda.current_stream(self.scene.device).wait_stream(self.streams[slot])
+
+    def synchronize(self) -> None:
+        for st in self.streams:
+            st.synchronize()
+
+    def stats(self, slot: int = 0) -> Dict[str, int]:
+        with torch.cuda.stream(self.streams[slot]):
+            return self.rasterizers[slot].stats()
