@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 200 /* 0.2.0: gsr_preprocess_geometry/_color removed (measured slower), gsr_read_stats takes a non-const workspace */
+#define GSR_VERSION 201 /* 0.2.1: + gsr_render_batch_slots.  0.2.0: gsr_preprocess_geometry/_color removed (measured slower), gsr_read_stats takes
+                            a non-const workspace */
 
 typedef enum GsrStatus {
     GSR_OK = 0,
@@ -174,6 +175,15 @@ int gsr_render_forward(const GsrScene *scene, const GsrCamera *cam, const GsrOpt
 int gsr_render_batch(const GsrScene *scene, const GsrCamera *cams /* [host] */, int32_t n_cams, const GsrOptions *opts,
                      int64_t max_pairs, void *workspace, size_t workspace_bytes, void *out_images, int64_t frame_stride,
                      void *stream);
+
+/* The same with n_slots frames in flight: view i is enqueued with workspaces[i % n_slots] on streams[i % n_slots], so that one
+ * view's HBM-bound stages overlap another's VALU-bound blend (the library keeps no state; each slot is one more
+ * (workspace, stream) pair, every workspace of workspace_bytes).  Frames are bit-identical to gsr_render_batch.  Each
+ * workspace's counters afterwards describe the LAST view it rendered; an overflow in any of its views is sticky in them.
+ * The caller orders the streams against whatever produced the scene and whatever consumes the frames. */
+int gsr_render_batch_slots(const GsrScene *scene, const GsrCamera *cams /* [host] */, int32_t n_cams, const GsrOptions *opts,
+                           int64_t max_pairs, void *const *workspaces /* [host] n_slots device pointers */, size_t workspace_bytes,
+                           void *const *streams /* [host] n_slots streams */, int32_t n_slots, void *out_images, int64_t frame_stride);
 
 /* Totals the blend's per-workgroup counters (one small kernel on `stream`: wave_entries / fetched_entries describe the
  * LAST gsr_blend of the frame, 0 if none ran; the two totals are written into the workspace's counter block, no frame

@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} declared in include/gsr.h but not exported by libgsr.so"
     assert sorted(_lib.EXPORTS) == names
-    assert _lib.lib.gsr_version() == 200
+    assert _lib.lib.gsr_version() == 201
 
 
 def test_struct_sizes_match_header():

@@ -152,6 +152,48 @@ def test_multi_camera_batch(G):
     assert not torch.equal(singles[0], singles[1])
 
 
+def test_frames_in_flight_are_bit_identical_to_single_stream(G):
+    """renderer.FramesInFlight / gsr_render_batch_slots: independent frames on separate HIP streams, one workspace each
+    (bench.py's throughput mode).  Same kernels on the same inputs, so every frame must equal the single-stream render bit
+    for bit — whole frames and shards, submit() and the batch entry point, including its overflow recovery."""
+    cols, cam0, _ = _medium(G, n=60_000)
+    W, H = cam0.width, cam0.height
+    fx = G.synthetic.pinhole_focal(W)
+    cams = [G.renderer.make_camera(p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H) for p in G.synthetic.ring_cameras(25)[::3]]
+    scene = G.renderer.GaussianScene.from_columns(cols)
+    ref = G.renderer.Rasterizer(scene)
+    singles = torch.stack([ref.render(c) for c in cams])
+    fif = G.renderer.FramesInFlight(scene, slots=3, max_pairs=ref.max_pairs)
+    outs = [torch.empty((H, W, 3), device="cuda") for _ in cams]
+    for _ in range(2):                                   # twice: every slot's workspace is reused
+        for c, o in zip(cams, outs):
+            fif.submit(c, out=o)
+    fif.synchronize()
+    assert torch.equal(torch.stack(outs), singles)
+    assert torch.equal(fif.render_batch(cams), singles)
+    small = G.renderer.FramesInFlight(scene, slots=2, max_pairs=2048)   # too small: an overflow in ANY slot must be caught
+    assert torch.equal(small.render_batch(cams), singles) and small.rasterizers[0].max_pairs > 2048
+    # shards (the multi-GPU ranks' mode), 8 rows apart: the three-phase shard preprocess on every slot
+    mk = G.renderer.make_options
+    o8 = mk(tile_row_begin=3, tile_row_step=8, output_layout=2)
+    strip = ref.render(cams[1], o8)
+    strips = [torch.zeros_like(strip) for _ in range(4)]
+    for s_ in strips:
+        fif.submit(cams[1], o8, out=s_)
+    fif.synchronize()
+    assert all(torch.equal(s_, strip) for s_ in strips) and strip.any()
+    lib = G.renderer.lib
+    import ctypes as C
+    sc = scene.c_struct()
+    arr = (G.renderer.GsrCamera * 2)(cams[0], cams[1])
+    ws = fif.rasterizers[0]._workspace(W, H)
+    out = torch.empty((2, H, W, 3), device="cuda")
+    two = (C.c_void_p * 2)(ws.data_ptr(), ws.data_ptr())
+    st = (C.c_void_p * 2)(0, 0)
+    assert lib.gsr_render_batch_slots(C.byref(sc), arr, 2, C.byref(mk()), fif.rasterizers[0].max_pairs, two, ws.numel(), st, 2,
+                                      out.data_ptr(), H * W * 3) != 0 and b"share a workspace" in lib.gsr_last_error()
+
+
 def test_matrix_pipe_blend_matches_vector_blend(G):
     """blend_impl = 2 evaluates the quadratic on the MFMA pipe (expanded polynomial: ~1e-5 absolute in the exponent).
     Same lists, same counters; frames within the oracle tolerance of each other and of the oracle."""

@@ -1,33 +1,52 @@
 #!/usr/bin/env python3
-"""One-GPU rehearsal of the tile-row sharding: time each rank's shard of the bench frame separately.
-The slowest shard (+ the framebuffer gather, not measured here) bounds the G-GPU frame time."""
+"""One-GPU rehearsal of the tile-row sharding: time each rank's shard of the bench frame separately, with one frame in flight
+(per-frame latency) and with `slots` frames in flight on separate streams (throughput, what bench.py --gpus N runs).
+The slowest shard (+ the framebuffer gather, not measured here) bounds the G-GPU frame time.
+usage: shard_timing.py [bicycle|garden] [G r]      ("G r": only that shard, e.g. under rocprofv3)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import gsr_amd
-from gsr_amd import renderer, synthetic, utils, dist as gdist
+from gsr_amd import renderer, synthetic, dist as gdist
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_834_784
-only = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else None   # "G r": just this shard (for a rocprofv3 timeline)
+args = sys.argv[1:]
+workload = args.pop(0) if args and not args[0].isdigit() else "bicycle"
+n, seed = {"bicycle": (6_131_954, 361), "garden": (5_834_784, 360)}[workload]
+only = (int(args[0]), int(args[1])) if len(args) > 1 else None
+SLOTS = int(os.environ.get("GSR_SLOTS", "4"))
 W, H = 1920, 1080
-cols = synthetic.mip360_like(n, 360)
+cols = synthetic.mip360_like(n, seed)
 p = synthetic.ring_cameras(25)[0]
 fx = synthetic.pinhole_focal(W)
 cam = renderer.make_camera(p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H)
 scene = renderer.GaussianScene.from_columns(cols)
+
+
+def timed(fif, opts, outs, frames=24):
+    S = fif.slots
+    for f in range(2 * S + 2):
+        fif.submit(cam, opts, out=outs[f % S], slot=f % S)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for f in range(frames):
+        fif.submit(cam, opts, out=outs[f % S], slot=f % S)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / frames * 1e3
+
+
 for G in (1, 2, 4, 8) if only is None else (only[0],):
     plan = gdist.TileRowPlan(H, W, G)
-    times, vis, pairs = [], [], []
+    one, many, vis, pairs = [], [], [], []
     for r in range(G) if only is None else (only[1],):
-        R = renderer.Rasterizer(scene)
         opts = renderer.make_options(**plan.shard_options(r)) if G > 1 else renderer.make_options()
-        R.fit_pairs(cam, opts)
-        out = torch.zeros(plan.strip_shape(r) if G > 1 else (H, W, 3), device="cuda")
-        for _ in range(3): R.enqueue(cam, opts, out)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(20): R.enqueue(cam, opts, out)
-        torch.cuda.synchronize(); times.append((time.perf_counter() - t0) / 20 * 1e3)
-        st = R.stats(); vis.append(st["n_visible"]); pairs.append(st["n_pairs"])
-    print(f"G={G}: shard ms min {min(times):.3f} max {max(times):.3f}  visible/shard {min(vis)}..{max(vis)}  pairs/shard {min(pairs)}..{max(pairs)}  "
-          f"=> speedup bound {times[0] if G == 1 else 0:.3f}" if G == 1 else
-          f"G={G}: shard ms min {min(times):.3f} max {max(times):.3f}  visible/shard {min(vis)}..{max(vis)}  pairs/shard {min(pairs)}..{max(pairs)}")
+        shape = plan.strip_shape(r) if G > 1 else (H, W, 3)
+        fif = renderer.FramesInFlight(scene, slots=SLOTS)
+        fif.set_max_pairs(fif.rasterizers[0].fit_pairs(cam, opts))
+        outs = [torch.zeros(shape, device="cuda") for _ in range(SLOTS)]
+        single = renderer.FramesInFlight(scene, slots=1, max_pairs=fif.rasterizers[0].max_pairs)
+        timed(single, opts, outs[:1], 6)  # warm the clocks before the first measurement of the process
+        one.append(timed(single, opts, outs[:1]))
+        many.append(timed(fif, opts, outs))
+        st = fif.stats(0); vis.append(st["n_visible"]); pairs.append(st["n_pairs"])
+        del fif, single, outs
+    print(f"{workload} G={G}: shard ms, one frame in flight: min {min(one):.3f} max {max(one):.3f} | {SLOTS} in flight: min {min(many):.3f} "
+          f"max {max(many):.3f} | visible/shard {min(vis)}..{max(vis)}  list entries/shard {min(pairs)}..{max(pairs)}", flush=True)

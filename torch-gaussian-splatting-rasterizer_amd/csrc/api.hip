@@ -304,6 +304,31 @@ int gsr_render_batch(const GsrScene *scene, const GsrCamera *cams, int32_t n_cam
     return GSR_OK;
 }
 
+int gsr_render_batch_slots(const GsrScene *scene, const GsrCamera *cams, int32_t n_cams, const GsrOptions *opts, int64_t max_pairs,
+                           void *const *workspaces, size_t workspace_bytes, void *const *streams, int32_t n_slots, void *out_images,
+                           int64_t frame_stride)
+{
+    if (!cams || n_cams < 0 || !out_images || !opts || !workspaces || !streams || n_slots < 1) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
+    for (int32_t k = 0; k < n_slots; ++k) {
+        if (!workspaces[k]) { set_error("null workspace in slot %d", (int)k); return GSR_ERR_BAD_ARG; }
+        for (int32_t j = 0; j < k; ++j)
+            if (workspaces[j] == workspaces[k]) { set_error("slots %d and %d share a workspace", (int)j, (int)k); return GSR_ERR_BAD_ARG; }
+    }
+    for (int32_t i = 0; i < n_cams; ++i) {
+        if (cams[i].width != cams[0].width || cams[i].height != cams[0].height) { set_error("views of a batch must share one frame size"); return GSR_ERR_BAD_ARG; }
+        if (frame_stride < (int64_t)cams[i].width * cams[i].height * 3) { set_error("frame_stride smaller than a frame"); return GSR_ERR_BAD_ARG; }
+    }
+    for (int32_t i = 0; i < n_cams; ++i) {
+        const int32_t k = i % n_slots;
+        // a slot's first view clears its whole control block, its later views keep the batch-sticky overflow words
+        int rc = render_forward_impl(scene, &cams[i], opts, max_pairs, workspaces[k], workspace_bytes,
+                                     static_cast<char *>(out_images) + (size_t)i * frame_stride * (opts->output_dtype == 1 ? 2 : 4), nullptr,
+                                     streams[k], i >= n_slots);
+        if (rc) return rc;
+    }
+    return GSR_OK;
+}
+
 int gsr_read_stats(void *workspace, size_t workspace_bytes, GsrStats *out, void *stream)
 {
     if (!workspace || !out || workspace_bytes < sizeof(FrameCtrl)) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }

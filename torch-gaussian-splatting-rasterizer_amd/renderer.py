@@ -288,6 +288,47 @@ class FramesInFlight:
             self.rasterizers[k].enqueue(cam, opts, out=out)
         return k
 
+    def render_batch(self, cams, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Rasterizer.render_batch with the views spread round robin over the slots (gsr_render_batch_slots): [B,H,W,3],
+        bit-identical to the single-stream batch.  The current stream waits for every slot before this returns; a view that
+        overflows the pair buffers makes the batch re-run with room for it."""
+        opts = opts or make_options()
+        if opts.output_layout != 0 or opts.tile_row_step > 1:
+            raise ValueError("render_batch renders whole [H,W,3] frames")
+        cams = list(cams)
+        arr = (GsrCamera * len(cams))(*cams)
+        W, H = cams[0].width, cams[0].height
+        dev = self.scene.device
+        dtype = torch.bfloat16 if opts.output_dtype == 1 else torch.float32
+        if out is None:
+            out = torch.empty((len(cams), H, W, 3), dtype=dtype, device=dev)
+        elif tuple(out.shape) != (len(cams), H, W, 3) or out.dtype != dtype or not out.is_contiguous() or not out.is_cuda:
+            raise ValueError(f"out must be a contiguous {dtype} CUDA tensor of shape {(len(cams), H, W, 3)}")
+        sc = self.scene.c_struct()
+        n = len(self.rasterizers)
+        cur = torch.cuda.current_stream(dev)
+        while True:
+            wss = [r._workspace(W, H) for r in self.rasterizers]  # all of one size: the slots share max_pairs
+            for st in self.streams:
+                st.wait_stream(cur)  # `out` (and the workspaces) may have been allocated / used on the current stream
+            ws_arr = (C.c_void_p * n)(*[w.data_ptr() for w in wss])
+            st_arr = (C.c_void_p * n)(*[int(st.cuda_stream) for st in self.streams])
+            check(lib.gsr_render_batch_slots(C.byref(sc), arr, len(cams), C.byref(opts), self.rasterizers[0].max_pairs, ws_arr,
+                                             wss[0].numel(), st_arr, n, out.data_ptr(), H * W * 3))
+            for r in self.rasterizers:
+                r._rendered = True
+            need = 0
+            for k in range(min(n, len(cams))):
+                try:
+                    self.stats(k)
+                except _lib.GsrPairOverflow:
+                    need = max(need, int(self.rasterizers[k].last_stats["n_pairs_bbox"]))
+            for k in range(n):
+                self.wait(k)
+            if need == 0:
+                return out
+            self.set_max_pairs(int(min(_lib.GSR_MAX_PAIRS, need + need // 4 + 1024)))
+
     def wait(self, slot: int) -> None:
         torch.cuda.current_stream(self.scene.device).wait_stream(self.streams[slot])
 
