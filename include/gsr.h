@@ -12,8 +12,10 @@
  *   - all device work is enqueued on the caller's hipStream_t (passed as void*); nothing synchronises
  *     except gsr_read_stats.
  *   - fp32 throughout (the reference's arithmetic type); device pointers unless marked [host].
- *   - one environment switch is read per call, for A/B timing and tests only: GSR_FINE_BINNING=1 generates the (gaussian, tile)
- *     pairs per 16x16 tile directly instead of per 32x32 cell + expansion (same frames; csrc/binning.hip).
+ *   - two environment switches exist, for A/B timing and tests only (same frames either way): GSR_FINE_BINNING=1 (read per
+ *     call) generates the (gaussian, tile) pairs per 16x16 tile directly instead of per 32x32 cell + expansion
+ *     (csrc/binning.hip); GSR_SHARD_PREPROCESS=0/1 (read once per process) forces the whole-frame / the three-phase
+ *     preprocess for tile-row shards instead of choosing by tile_row_step (csrc/preprocess.hip).
  */
 #ifndef GSR_H
 #define GSR_H

@@ -11,7 +11,8 @@ mkdir -p "$OUT"
 OUT=$(cd "$OUT" && pwd)
 export TMPDIR=/tmp
 cd /tmp || exit 1
-B="$ROOT/bench.py --workload $WL --no-cpu-baseline --no-psnr --legs= ${BENCH_EXTRA:-}"
+# one frame in flight: kernels of overlapping frames share the machine, their durations are not attributable
+B="$ROOT/bench.py --workload $WL --no-cpu-baseline --no-psnr --legs= --frames-in-flight 1 ${BENCH_EXTRA:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o trace -- python3 $B --steps 30 --warmup 5 > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err" &&
 for spec in "FETCH_SIZE:FETCH_SIZE" "WRITE_SIZE:WRITE_SIZE" \
             "sq:SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
