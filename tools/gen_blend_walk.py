@@ -17,11 +17,17 @@ def update(o0, T, Cr, Cg, Cb):
             f"v_fma_f32 {Cb}, v40, v{o0 + 3}, {Cb}", f"v_fma_f32 {T}, -{T}, v63, {T}", "s_mov_b64 exec, -1"]
 
 
+OUT_OF_LINE = []  # guarded evaluations: the rarer case (~20 %) leaves the straight-line path and jumps back
+
+
 def guarded_or_not(fastmask, idx, o0, st):
-    lf, lj = next(label), next(label)
+    lg, lj = next(label), next(label)
     full = [f"v_cmpx_le_f32 vcc, v62, v{o0}", f"v_min_f32 v63, {MAXA}, v63", f"v_cmpx_lt_f32 vcc, {MINA}, v63"] + update(o0, *st)
-    fast = ["s_nop 0", f"v_cmpx_lt_f32 vcc, {MINA}, v63"] + update(o0, *st)
-    return [f"s_bitcmp1_b64 {fastmask}, {idx}", f"s_cbranch_scc1 {lf}f"] + full + [f"s_branch {lj}f", f"{lf}:"] + fast + [f"{lj}:"]
+    # (the s_bitcmp1 + s_cbranch below sit between v_exp_f32 and its first consumer: the one wait state a transcendental's
+    # result needs on gfx940+; the guarded path starts with a v_cmpx that does not read it)
+    fast = [f"v_cmpx_lt_f32 vcc, {MINA}, v63"] + update(o0, *st)
+    OUT_OF_LINE.extend([f"{lg}:"] + full + [f"s_branch {lj}b"])
+    return [f"s_bitcmp1_b64 {fastmask}, {idx}", f"s_cbranch_scc0 {lg}f"] + fast + [f"{lj}:"]
 
 
 def load(idx, addr, g0, c0, o0):
@@ -51,7 +57,7 @@ def walk(ev):
     lines += ["1:", "s_cmp_eq_u64 %[m], 0", "s_cbranch_scc1 3f"] + load(IB, 41, *B) + ["s_waitcnt lgkmcnt(3)"] + ev(IA, *A)
     lines += ["s_cmp_eq_u64 %[m], 0", "s_cbranch_scc1 4f"] + load(IA, 40, *A) + ["s_waitcnt lgkmcnt(3)"] + ev(IB, *B) + ["s_branch 1b"]
     lines += ["3:", "s_waitcnt lgkmcnt(0)"] + ev(IA, *A) + ["s_branch 5f"]
-    lines += ["4:", "s_waitcnt lgkmcnt(0)"] + ev(IB, *B) + ["5:"]
+    lines += ["4:", "s_waitcnt lgkmcnt(0)"] + ev(IB, *B) + ["s_branch 5f"] + OUT_OF_LINE + ["5:"]
     return lines
 
 

@@ -67,11 +67,14 @@ __device__ __forceinline__ void blend_one(const float2 g, const float4 c, const 
 //     EXEC.  tools/valu_microbench.hip: v_cmp to an SGPR pair 1.76 ns and the v_cndmask that consumes it 1.83 ns per
 //     wave-instruction per SIMD, v_cmpx 1.1 ns like any plain VALU.  Lanes that fail keep C and T untouched, which is what
 //     adding w = 0 did.
-//   - v_cmpx_le (or an s_nop) sits between v_exp_f32 and its consumer: on gfx940+ a VALU reading a transcendental's result
-//     needs one wait state; the compiler inserts it for its own code, never inside inline asm (without it the first four lanes
-//     of every eight read a stale value — found by tools/cmpx_test.hip).
+//   - something always sits between v_exp_f32 and its consumer (the guarded path's v_cmpx_le, the unguarded path's scalar bit
+//     test + branch): on gfx940+ a VALU reading a transcendental's result needs one wait state; the compiler inserts it for
+//     its own code, never inside inline asm (without it the first four lanes of every eight read a stale value — found by
+//     tools/cmpx_test.hip).
 //   - records flagged `fa` / `fb` by the culling lane (footprint_classify: neither the 0.99 clamp nor the `p <= L` test can
-//     fire anywhere on that quadrant) take an evaluation without v_min and the second v_cmpx;
+//     fire anywhere on that quadrant) take an evaluation without v_min and the second v_cmpx; that is the common case (~80 %)
+//     and the straight-line one, the guarded evaluations sit out of line behind the loop (tools/walk_latency.hip: a wave
+//     alone 127 -> 111 ns per record with both quadrants hit, at 8 waves per SIMD 152 -> 132 ns = the LDS limit below);
 //   - the walk itself costs ~6 scalar instructions per record (s_ff1 + s_bitset0 pop, bit tests, EXEC restore) instead of the
 //     compiler's 10.8 per evaluation, and the accumulators never change registers (the compiler's loop copied them every trip);
 //   - records roll through two register sets: while record k is evaluated the reads of record k+1 are in flight (counted
@@ -122,19 +125,7 @@ __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned l
         "v_fma_f32 v62, v40, v62, v39\n\t"
         "v_exp_f32 v63, v62\n\t"
         "s_bitcmp1_b64 %[fa], %[ia]\n\t"
-        "s_cbranch_scc1 11f\n\t"
-        "v_cmpx_le_f32 vcc, v62, v48\n\t"
-        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
-        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
-        "v_mul_f32 v40, %[Ta], v63\n\t"
-        "v_fma_f32 %[Cra], v40, v49, %[Cra]\n\t"
-        "v_fma_f32 %[Cga], v40, v50, %[Cga]\n\t"
-        "v_fma_f32 %[Cba], v40, v51, %[Cba]\n\t"
-        "v_fma_f32 %[Ta], -%[Ta], v63, %[Ta]\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_branch 12f\n\t"
-        "11:\n\t"
-        "s_nop 0\n\t"
+        "s_cbranch_scc0 11f\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
         "v_mul_f32 v40, %[Ta], v63\n\t"
         "v_fma_f32 %[Cra], v40, v49, %[Cra]\n\t"
@@ -152,19 +143,7 @@ __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned l
         "v_fma_f32 v62, v40, v62, v39\n\t"
         "v_exp_f32 v63, v62\n\t"
         "s_bitcmp1_b64 %[fb], %[ia]\n\t"
-        "s_cbranch_scc1 14f\n\t"
-        "v_cmpx_le_f32 vcc, v62, v48\n\t"
-        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
-        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
-        "v_mul_f32 v40, %[Tb], v63\n\t"
-        "v_fma_f32 %[Crb], v40, v49, %[Crb]\n\t"
-        "v_fma_f32 %[Cgb], v40, v50, %[Cgb]\n\t"
-        "v_fma_f32 %[Cbb], v40, v51, %[Cbb]\n\t"
-        "v_fma_f32 %[Tb], -%[Tb], v63, %[Tb]\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_branch 15f\n\t"
-        "14:\n\t"
-        "s_nop 0\n\t"
+        "s_cbranch_scc0 14f\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
         "v_mul_f32 v40, %[Tb], v63\n\t"
         "v_fma_f32 %[Crb], v40, v49, %[Crb]\n\t"
@@ -194,19 +173,7 @@ __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned l
         "v_fma_f32 v62, v40, v62, v39\n\t"
         "v_exp_f32 v63, v62\n\t"
         "s_bitcmp1_b64 %[fa], %[ib]\n\t"
-        "s_cbranch_scc1 17f\n\t"
-        "v_cmpx_le_f32 vcc, v62, v58\n\t"
-        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
-        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
-        "v_mul_f32 v40, %[Ta], v63\n\t"
-        "v_fma_f32 %[Cra], v40, v59, %[Cra]\n\t"
-        "v_fma_f32 %[Cga], v40, v60, %[Cga]\n\t"
-        "v_fma_f32 %[Cba], v40, v61, %[Cba]\n\t"
-        "v_fma_f32 %[Ta], -%[Ta], v63, %[Ta]\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_branch 18f\n\t"
-        "17:\n\t"
-        "s_nop 0\n\t"
+        "s_cbranch_scc0 17f\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
         "v_mul_f32 v40, %[Ta], v63\n\t"
         "v_fma_f32 %[Cra], v40, v59, %[Cra]\n\t"
@@ -224,19 +191,7 @@ __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned l
         "v_fma_f32 v62, v40, v62, v39\n\t"
         "v_exp_f32 v63, v62\n\t"
         "s_bitcmp1_b64 %[fb], %[ib]\n\t"
-        "s_cbranch_scc1 20f\n\t"
-        "v_cmpx_le_f32 vcc, v62, v58\n\t"
-        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
-        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
-        "v_mul_f32 v40, %[Tb], v63\n\t"
-        "v_fma_f32 %[Crb], v40, v59, %[Crb]\n\t"
-        "v_fma_f32 %[Cgb], v40, v60, %[Cgb]\n\t"
-        "v_fma_f32 %[Cbb], v40, v61, %[Cbb]\n\t"
-        "v_fma_f32 %[Tb], -%[Tb], v63, %[Tb]\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_branch 21f\n\t"
-        "20:\n\t"
-        "s_nop 0\n\t"
+        "s_cbranch_scc0 20f\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
         "v_mul_f32 v40, %[Tb], v63\n\t"
         "v_fma_f32 %[Crb], v40, v59, %[Crb]\n\t"
@@ -260,19 +215,7 @@ __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned l
         "v_fma_f32 v62, v40, v62, v39\n\t"
         "v_exp_f32 v63, v62\n\t"
         "s_bitcmp1_b64 %[fa], %[ia]\n\t"
-        "s_cbranch_scc1 23f\n\t"
-        "v_cmpx_le_f32 vcc, v62, v48\n\t"
-        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
-        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
-        "v_mul_f32 v40, %[Ta], v63\n\t"
-        "v_fma_f32 %[Cra], v40, v49, %[Cra]\n\t"
-        "v_fma_f32 %[Cga], v40, v50, %[Cga]\n\t"
-        "v_fma_f32 %[Cba], v40, v51, %[Cba]\n\t"
-        "v_fma_f32 %[Ta], -%[Ta], v63, %[Ta]\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_branch 24f\n\t"
-        "23:\n\t"
-        "s_nop 0\n\t"
+        "s_cbranch_scc0 23f\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
         "v_mul_f32 v40, %[Ta], v63\n\t"
         "v_fma_f32 %[Cra], v40, v49, %[Cra]\n\t"
@@ -290,19 +233,7 @@ __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned l
         "v_fma_f32 v62, v40, v62, v39\n\t"
         "v_exp_f32 v63, v62\n\t"
         "s_bitcmp1_b64 %[fb], %[ia]\n\t"
-        "s_cbranch_scc1 26f\n\t"
-        "v_cmpx_le_f32 vcc, v62, v48\n\t"
-        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
-        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
-        "v_mul_f32 v40, %[Tb], v63\n\t"
-        "v_fma_f32 %[Crb], v40, v49, %[Crb]\n\t"
-        "v_fma_f32 %[Cgb], v40, v50, %[Cgb]\n\t"
-        "v_fma_f32 %[Cbb], v40, v51, %[Cbb]\n\t"
-        "v_fma_f32 %[Tb], -%[Tb], v63, %[Tb]\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_branch 27f\n\t"
-        "26:\n\t"
-        "s_nop 0\n\t"
+        "s_cbranch_scc0 26f\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
         "v_mul_f32 v40, %[Tb], v63\n\t"
         "v_fma_f32 %[Crb], v40, v49, %[Crb]\n\t"
@@ -326,19 +257,7 @@ __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned l
         "v_fma_f32 v62, v40, v62, v39\n\t"
         "v_exp_f32 v63, v62\n\t"
         "s_bitcmp1_b64 %[fa], %[ib]\n\t"
-        "s_cbranch_scc1 29f\n\t"
-        "v_cmpx_le_f32 vcc, v62, v58\n\t"
-        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
-        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
-        "v_mul_f32 v40, %[Ta], v63\n\t"
-        "v_fma_f32 %[Cra], v40, v59, %[Cra]\n\t"
-        "v_fma_f32 %[Cga], v40, v60, %[Cga]\n\t"
-        "v_fma_f32 %[Cba], v40, v61, %[Cba]\n\t"
-        "v_fma_f32 %[Ta], -%[Ta], v63, %[Ta]\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_branch 30f\n\t"
-        "29:\n\t"
-        "s_nop 0\n\t"
+        "s_cbranch_scc0 29f\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
         "v_mul_f32 v40, %[Ta], v63\n\t"
         "v_fma_f32 %[Cra], v40, v59, %[Cra]\n\t"
@@ -356,19 +275,7 @@ __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned l
         "v_fma_f32 v62, v40, v62, v39\n\t"
         "v_exp_f32 v63, v62\n\t"
         "s_bitcmp1_b64 %[fb], %[ib]\n\t"
-        "s_cbranch_scc1 32f\n\t"
-        "v_cmpx_le_f32 vcc, v62, v58\n\t"
-        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
-        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
-        "v_mul_f32 v40, %[Tb], v63\n\t"
-        "v_fma_f32 %[Crb], v40, v59, %[Crb]\n\t"
-        "v_fma_f32 %[Cgb], v40, v60, %[Cgb]\n\t"
-        "v_fma_f32 %[Cbb], v40, v61, %[Cbb]\n\t"
-        "v_fma_f32 %[Tb], -%[Tb], v63, %[Tb]\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_branch 33f\n\t"
-        "32:\n\t"
-        "s_nop 0\n\t"
+        "s_cbranch_scc0 32f\n\t"
         "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
         "v_mul_f32 v40, %[Tb], v63\n\t"
         "v_fma_f32 %[Crb], v40, v59, %[Crb]\n\t"
@@ -378,6 +285,95 @@ __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned l
         "s_mov_b64 exec, -1\n\t"
         "33:\n\t"
         "31:\n\t"
+        "s_branch 5f\n\t"
+        "11:\n\t"
+        "v_cmpx_le_f32 vcc, v62, v48\n\t"
+        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[Ta], v63\n\t"
+        "v_fma_f32 %[Cra], v40, v49, %[Cra]\n\t"
+        "v_fma_f32 %[Cga], v40, v50, %[Cga]\n\t"
+        "v_fma_f32 %[Cba], v40, v51, %[Cba]\n\t"
+        "v_fma_f32 %[Ta], -%[Ta], v63, %[Ta]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 12b\n\t"
+        "14:\n\t"
+        "v_cmpx_le_f32 vcc, v62, v48\n\t"
+        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[Tb], v63\n\t"
+        "v_fma_f32 %[Crb], v40, v49, %[Crb]\n\t"
+        "v_fma_f32 %[Cgb], v40, v50, %[Cgb]\n\t"
+        "v_fma_f32 %[Cbb], v40, v51, %[Cbb]\n\t"
+        "v_fma_f32 %[Tb], -%[Tb], v63, %[Tb]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 15b\n\t"
+        "17:\n\t"
+        "v_cmpx_le_f32 vcc, v62, v58\n\t"
+        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[Ta], v63\n\t"
+        "v_fma_f32 %[Cra], v40, v59, %[Cra]\n\t"
+        "v_fma_f32 %[Cga], v40, v60, %[Cga]\n\t"
+        "v_fma_f32 %[Cba], v40, v61, %[Cba]\n\t"
+        "v_fma_f32 %[Ta], -%[Ta], v63, %[Ta]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 18b\n\t"
+        "20:\n\t"
+        "v_cmpx_le_f32 vcc, v62, v58\n\t"
+        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[Tb], v63\n\t"
+        "v_fma_f32 %[Crb], v40, v59, %[Crb]\n\t"
+        "v_fma_f32 %[Cgb], v40, v60, %[Cgb]\n\t"
+        "v_fma_f32 %[Cbb], v40, v61, %[Cbb]\n\t"
+        "v_fma_f32 %[Tb], -%[Tb], v63, %[Tb]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 21b\n\t"
+        "23:\n\t"
+        "v_cmpx_le_f32 vcc, v62, v48\n\t"
+        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[Ta], v63\n\t"
+        "v_fma_f32 %[Cra], v40, v49, %[Cra]\n\t"
+        "v_fma_f32 %[Cga], v40, v50, %[Cga]\n\t"
+        "v_fma_f32 %[Cba], v40, v51, %[Cba]\n\t"
+        "v_fma_f32 %[Ta], -%[Ta], v63, %[Ta]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 24b\n\t"
+        "26:\n\t"
+        "v_cmpx_le_f32 vcc, v62, v48\n\t"
+        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[Tb], v63\n\t"
+        "v_fma_f32 %[Crb], v40, v49, %[Crb]\n\t"
+        "v_fma_f32 %[Cgb], v40, v50, %[Cgb]\n\t"
+        "v_fma_f32 %[Cbb], v40, v51, %[Cbb]\n\t"
+        "v_fma_f32 %[Tb], -%[Tb], v63, %[Tb]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 27b\n\t"
+        "29:\n\t"
+        "v_cmpx_le_f32 vcc, v62, v58\n\t"
+        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[Ta], v63\n\t"
+        "v_fma_f32 %[Cra], v40, v59, %[Cra]\n\t"
+        "v_fma_f32 %[Cga], v40, v60, %[Cga]\n\t"
+        "v_fma_f32 %[Cba], v40, v61, %[Cba]\n\t"
+        "v_fma_f32 %[Ta], -%[Ta], v63, %[Ta]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 30b\n\t"
+        "32:\n\t"
+        "v_cmpx_le_f32 vcc, v62, v58\n\t"
+        "v_min_f32 v63, 0x3f7d70a4, v63\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v63\n\t"
+        "v_mul_f32 v40, %[Tb], v63\n\t"
+        "v_fma_f32 %[Crb], v40, v59, %[Crb]\n\t"
+        "v_fma_f32 %[Cgb], v40, v60, %[Cgb]\n\t"
+        "v_fma_f32 %[Cbb], v40, v61, %[Cbb]\n\t"
+        "v_fma_f32 %[Tb], -%[Tb], v63, %[Tb]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 33b\n\t"
         "5:\n\t"
         : [Ta] "+v"(Ta), [Cra] "+v"(Cra), [Cga] "+v"(Cga), [Cba] "+v"(Cba), [Tb] "+v"(Tb), [Crb] "+v"(Crb), [Cgb] "+v"(Cgb),
           [Cbb] "+v"(Cbb), [m] "+s"(m), [ia] "=&s"(ia), [ib] "=&s"(ib)
@@ -597,9 +593,13 @@ __global__ __launch_bounds__(256 / QPW, 8) void blend_walk_kernel(BlendArgs a)
             const unsigned long long mA = doneA ? 0ull : __ballot(fa.hit), mB = (QPW == 1 || doneB) ? 0ull : __ballot(fb.hit);
             const unsigned long long fA = __ballot(fa.fast), fB = QPW == 1 ? 0ull : __ballot(fb.fast);
             evaluated += (uint32_t)__popcll(mA) + (uint32_t)__popcll(mB);
+#ifndef GSR_BLEND_NO_WALK  // analysis build: everything but the walks (staging, culling, barriers, tail)
             if (mA | mB)
                 blend_walk2_asm<BATCH * 16>(mA | mB, mA, mB, fA, fB, lds_rec + (unsigned)chunk * 16u, fpxA, fpxB, fpy, TA, CrA, CgA, CbA, TB,
                                             CrB, CgB, CbB);
+#else
+            TA += __builtin_popcountll(fA) * 1e-9f; TB += __builtin_popcountll(fB) * 1e-9f;
+#endif
             if (!doneA && __all(TA <= a.early_T)) doneA = true;
             if (QPW == 2 && !doneB && __all(TB <= a.early_T)) doneB = true;
             if (doneA && doneB) {
