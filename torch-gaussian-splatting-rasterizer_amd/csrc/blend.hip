@@ -74,7 +74,7 @@ __device__ __forceinline__ void blend_one(const float2 g, const float4 c, const 
 //   - records flagged `fa` / `fb` by the culling lane (footprint_classify: neither the 0.99 clamp nor the `p <= L` test can
 //     fire anywhere on that quadrant) take an evaluation without v_min and the second v_cmpx; that is the common case (~80 %)
 //     and the straight-line one, the guarded evaluations sit out of line behind the loop (tools/walk_latency.hip: a wave
-//     alone 127 -> 111 ns per record with both quadrants hit, at 8 waves per SIMD 152 -> 132 ns = the LDS limit below);
+//     alone 127 -> 111 ns per record with both quadrants hit, at 8 waves per SIMD 152 -> 132 ns);
 //   - the walk itself costs ~6 scalar instructions per record (s_ff1 + s_bitset0 pop, bit tests, EXEC restore) instead of the
 //     compiler's 10.8 per evaluation, and the accumulators never change registers (the compiler's loop copied them every trip);
 //   - records roll through two register sets: while record k is evaluated the reads of record k+1 are in flight (counted
