@@ -385,6 +385,46 @@ def test_tile_row_shards_reassemble_bit_exactly(G, step):
     assert pairs >= R.last_stats["n_pairs"] > 0                 # shards cull per-tile a little less (smaller rects)
 
 
+def test_three_phase_shard_preprocess_on_its_other_paths(G):
+    """preprocess.hip: ranks of 5+ shards find their gaussians with shard_preprocess_kernel (bound -> geometry -> colour, runs
+    compacted for the depth sort).  test_tile_row_shards_reassemble_bit_exactly covers it at step 8 on the packed-rect fp32
+    path; here the remaining instantiations, all bit for bit against the whole frame: fp16 SH storage, a frame wider than
+    256 tiles (rects gathered by id, no packed payload through the sort), GSR_SHARD_PREPROCESS-independent debug outputs
+    (a debug call on a shard still fills every gaussian's intermediates, then renders the shard correctly)."""
+    mk = G.renderer.make_options
+
+    def reassembles(R, cam, step):
+        full = R.render(cam)
+        tiles_y = (cam.height + 15) // 16
+        out = torch.zeros_like(full)
+        for r in range(step):
+            strip = R.render(cam, mk(tile_row_begin=r, tile_row_step=step, output_layout=2))
+            for k, ty in enumerate(range(r, tiles_y, step)):
+                h = min(16, cam.height - ty * 16)
+                out[ty * 16: ty * 16 + h] = strip[k * 16: k * 16 + h]
+        return torch.equal(out, full) and bool(full.any())
+
+    cols, cam, _ = _medium(G, n=80_000, W=640, H=360)
+    assert reassembles(G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols, sh_half=True)), cam, 5)
+    # wide frame: 263 tile columns x 13 tile rows
+    W, H = 4200, 200
+    wcols = G.synthetic.mip360_like(60_000, 12)
+    for i in range(3):
+        wcols[f"scale_{i}"] = (wcols[f"scale_{i}"] + np.float32(1.0)).astype(np.float32)
+    p = G.synthetic.look_at_pose((0.0, -2.0, 0.1), (0, 0, 0), 1, "w.png")
+    fx = G.synthetic.pinhole_focal(W, 100.0)
+    wcam = G.renderer.make_camera(p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H)
+    assert reassembles(G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(wcols)), wcam, 6)
+    # debug outputs on a shard: every gaussian's intermediates, identical to the whole-frame call's
+    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
+    o8 = mk(tile_row_begin=2, tile_row_step=8, output_layout=2)
+    strip = R.render(cam, o8)
+    whole, shard = R.preprocess_debug(cam), R.preprocess_debug(cam, o8)
+    for k in whole:
+        assert torch.equal(whole[k], shard[k]), k
+    assert torch.equal(R.render(cam, o8), strip)
+
+
 def test_full_hd_one_million(G):
     """BASELINE-size frame (1920x1080), 1 M gaussians: oracle parity at full resolution."""
     cols, cam, ocam = _medium(G, n=1_000_000, seed=360, shift=0.0, W=1920, H=1080, pose=0)
