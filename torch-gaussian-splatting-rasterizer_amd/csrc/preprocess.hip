@@ -1,4 +1,6 @@
-// preprocess.hip — stage 1: one thread per gaussian, everything rasterize.py:354-420 computes per gaussian.
+// preprocess.hip — stage 1: everything rasterize.py:354-420 computes per gaussian.  preprocess_kernel: one thread per
+// gaussian (whole frames, and ranks of up to 4 shards); shard_preprocess_kernel: the same arithmetic in three dense phases for
+// ranks of 5+ shards (below).
 //
 // Built with -ffp-contract=off: every expression below keeps the reference's fp32 operation order
 // (file:line cited per block) so the step functions downstream (ceil of the radius, floor of the
@@ -21,7 +23,7 @@ struct Cam {
     float F[16];
     float cc[3];
     float fx, fy, limx, limy;
-    float w_sigma2;  // largest eigenvalue of A^T A, A = w2c[:3,:3] (1 for a unit qvec), padded: bounds |J A| in the shard early-out
+    float w_sigma2;  // largest eigenvalue of A^T A, A = w2c[:3,:3] (1 for a unit qvec), padded: bounds |J A| in the shard kernel's phase 1
     int W, H;
 };
 
