@@ -134,6 +134,7 @@ def timed_frames(R, cams, opts, out, steps, warmup, dev, slots=1):
 
     fif = renderer.FramesInFlight(R.scene, slots=slots, max_pairs=R.max_pairs)
     fif.rasterizers[0] = R
+    fif.set_sort_passes(R.sort_passes)
     outs = [out] + [torch.empty_like(out) for _ in range(slots - 1)]
     for i in range(warmup):
         fif.submit(cams[i % len(cams)], opts, out=outs[i % slots], slot=i % slots)
@@ -237,6 +238,7 @@ def main():
     # size the pair buffer to the heaviest view once (grows on overflow), outside the timed region
     need = max(R.fit_pairs(c, opts) for c in cams)
     fif.set_max_pairs(need)
+    fif.set_sort_passes(R.sort_passes)  # the depth-sort bound learned from the views' counters (GsrOptions.depth_sort_passes)
     R.render(cam, opts, out=strip_view)
     shard_stats = dict(R.last_stats)
     torch.cuda.synchronize(dev)
@@ -273,6 +275,7 @@ def main():
     single = None
     if S > 1:
         one = renderer.FramesInFlight(scene, slots=1, max_pairs=need)
+        one.set_sort_passes(R.sort_passes)
         st1 = {"i": 0}
         sf1 = None
         if world > 1:
@@ -308,7 +311,7 @@ def main():
             "config": {"workload": f"{'real' if real else args.workload}: {desc}", "gaussians": n, "width": W, "height": H,
                        "camera": args.camera if ncam == 1 else f"cycling over {ncam} cameras",
                        "sharding": f"tile rows interleaved over {world} GPU(s), RCCL gather to rank 0" if world > 1 else "none",
-                       "reference_compat": True, "early_out_T": args.early_out_T, "sh_storage": "f16" if args.sh_half else "f32",
+                       "reference_compat": True, "early_out_T": args.early_out_T, "depth_sort_passes": R.sort_passes, "sh_storage": "f16" if args.sh_half else "f32",
                        "frame_storage": "bf16 (fp32 accumulation)" if args.bf16_output else "f32",
                        "blend_impl": {0: "valu", 1: "valu, plain-C walk", 2: "mfma (experimental)"}.get(args.blend_impl, str(args.blend_impl))},
             "stats_rank0_shard": shard_stats,
@@ -329,7 +332,7 @@ def main():
 
         ws = R._workspace(W, H)
         sc = scene.c_struct()
-        full_opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl,
+        full_opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl, depth_sort_passes=R.sort_passes,
                                           **(plan.shard_options(rank) if world > 1 else {}))
         out = torch.empty(plan.strip_shape(rank) if world > 1 else (H, W, 3), dtype=torch.float32, device=dev)
         stream = torch.cuda.current_stream(dev)

@@ -27,15 +27,17 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 201 /* 0.2.1: + gsr_render_batch_slots.  0.2.0: gsr_preprocess_geometry/_color removed (measured slower), gsr_read_stats takes
-                            a non-const workspace */
+#define GSR_VERSION 300 /* 0.3.0: GsrOptions.depth_sort_passes, GsrStats.sort_passes, GSR_ERR_SORT_PASSES.  0.2.1: + gsr_render_batch_slots.
+                            0.2.0: gsr_preprocess_geometry/_color removed (measured slower), gsr_read_stats takes a non-const workspace */
 
 typedef enum GsrStatus {
     GSR_OK = 0,
     GSR_ERR_BAD_ARG = -1,       /* null pointer, non-positive size, unsupported option */
     GSR_ERR_WORKSPACE = -2,     /* workspace smaller than gsr_workspace_bytes() says */
     GSR_ERR_PAIR_OVERFLOW = -3, /* (gaussian,tile) pairs exceeded max_pairs: frame is incomplete, re-render with more */
-    GSR_ERR_HIP = -4            /* a HIP runtime call failed; see gsr_last_error() */
+    GSR_ERR_HIP = -4,           /* a HIP runtime call failed; see gsr_last_error() */
+    GSR_ERR_SORT_PASSES = -5    /* the frame's depth keys span more bits than GsrOptions.depth_sort_passes passes cover: the frame is
+                                   wrong, re-render with GsrStats.sort_passes (or 0) */
 } GsrStatus;
 
 /* Constants of rasterize.py:29-38 and the literals buried in the reference's glue. */
@@ -102,6 +104,11 @@ typedef struct GsrOptions {
                                  6 B per pixel (BASELINE configs[2]); T and the colour sums are ALWAYS accumulated in fp32
                                  registers — bf16 accumulators measure 41 dB, below the 50 dB bar.
                                  out_final_T stays float32. */
+    int32_t depth_sort_passes;/* 0 (default): enqueue the four radix passes any depth range can need; those a frame does not need
+                                 return at once, but still cost their launches (3 per pass, ~4.6 us each).  1..4: the caller's bound on
+                                 what the frames need — GsrStats.sort_passes of an earlier frame of the scene (3 whenever the depths stay
+                                 within 0.2 .. 13 000): only that many are enqueued.  Verified on the device like max_pairs: a frame
+                                 that needs more is flagged and gsr_read_stats returns GSR_ERR_SORT_PASSES. */
 } GsrOptions;
 
 /* Counters of one frame (device -> host with gsr_read_stats). */
@@ -110,9 +117,10 @@ typedef struct GsrStats {
     uint32_t n_pairs_bbox;  /* D: pair slots this frame needs, i.e. what max_pairs must cover: (gaussian, 32x32 cell) pairs of the
                                visible gaussians' rects (frames wider than 4096 px: (gaussian, 16x16 tile) pairs of this shard) */
     uint32_t n_pairs;       /* E: entries of the per-tile lists the blend consumes (this shard; after footprint culling) */
-    uint32_t overflow;      /* 1 if D exceeded max_pairs (frame incomplete) */
+    uint32_t overflow;      /* bit 0: D exceeded max_pairs (frame incomplete); bit 1: the depth sort needed more passes than
+                               depth_sort_passes allowed (frame wrong) */
     uint32_t max_list_len;  /* longest per-tile list */
-    uint32_t _pad;
+    uint32_t sort_passes;   /* radix passes the depth sort of this frame needs (1..4): the bound to pass as depth_sort_passes */
     uint64_t wave_entries;  /* (8x8 quadrant, entry) pairs the blend actually evaluated: 64 pixel evaluations each */
     uint64_t fetched_entries; /* list entries the blend staged (<= n_pairs: a saturated tile stops fetching) */
 } GsrStats;
@@ -190,7 +198,7 @@ int gsr_render_batch_slots(const GsrScene *scene, const GsrCamera *cams /* [host
 /* Totals the blend's per-workgroup counters (one small kernel on `stream`: wave_entries / fetched_entries describe the
  * LAST gsr_blend of the frame, 0 if none ran; the two totals are written into the workspace's counter block, no frame
  * data changes), copies the frame counters to host memory and waits for the stream.
- * Returns GSR_ERR_PAIR_OVERFLOW if the frame overflowed max_pairs. */
+ * Returns GSR_ERR_PAIR_OVERFLOW if the frame overflowed max_pairs, GSR_ERR_SORT_PASSES if depth_sort_passes was too small. */
 int gsr_read_stats(void *workspace, size_t workspace_bytes, GsrStats *out /* [host] */, void *stream);
 
 /* Stand-alone helpers behind the reference's helper functions (same maths as inside gsr_preprocess). */

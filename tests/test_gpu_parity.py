@@ -582,27 +582,30 @@ def test_c_abi_rejects_bad_arguments(G):
         _lib.workspace_bytes(10, 0, 10, 10)
 
 
-def _ctrl_word(R, cam, byte_offset):
-    """A 32-bit word of the workspace's counter block (gsr_internal.h FrameCtrl) — only the tests peek in there."""
-    ws = R._workspace(cam.width, cam.height)
-    torch.cuda.synchronize()
-    return int(ws[byte_offset: byte_offset + 4].view(torch.int32).item())
-
-
-SORT_PASSES_OFFSET = 40 + 512 * 4 + 8     # FrameCtrl: 40-byte GsrStats head, digit_tot[512], stats_off, stats_slots
-
-
 def test_depth_sort_plans_its_passes_from_the_key_range(G):
     """sort.hip: the depth sort runs on key - bits(0.2f) and only over the bits the frame uses.  An ordinary scene (depths
     0.2 .. 64) sorts in 3 passes (9 + 9 + 9 bits); the same scene blown up 1000x needs the fourth.  Both against the oracle,
-    and the order is exact in both (a wrong digit split would scramble the draw order)."""
+    and the order is exact in both (a wrong digit split would scramble the draw order).  GsrStats.sort_passes reports the
+    plan; GsrOptions.depth_sort_passes bounds what is enqueued, verified on the device: the same frame when the bound
+    holds, GSR_ERR_SORT_PASSES when it does not, and the Rasterizer learns the bound from the counters it reads."""
+    from gsr_amd import _lib
+
+    mk = G.renderer.make_options
     cols, cam, ocam = _medium(G, n=120_000)
     packed = G.utils.pack_gaussians(cols)
     R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(packed))
-    img = R.render(cam).cpu().numpy()
-    assert _ctrl_word(R, cam, SORT_PASSES_OFFSET) == 3
+    assert R.sort_passes == 0
+    img = R.render(cam)                                    # no bound yet: four passes enqueued, three run
+    assert R.last_stats["sort_passes"] == 3 and R.sort_passes == 3 and R.last_stats["overflow"] == 0
     oimg, _ = G.orc.render(packed, ocam)
-    assert_frames_close(img, oimg)
+    assert_frames_close(img.cpu().numpy(), oimg)
+    assert torch.equal(R.render(cam), img)                  # now with the learned bound: three passes enqueued
+    for k in (3, 4):
+        assert torch.equal(R.render(cam, mk(depth_sort_passes=k)), img)
+    with pytest.raises(_lib.GsrSortPasses):                 # the caller's own bound is not second-guessed
+        R.render(cam, mk(depth_sort_passes=2))
+    assert R.last_stats["sort_passes"] == 3 and R.last_stats["overflow"] == 2
+    assert torch.equal(R.render(cam), img)
     far = {k: v.copy() for k, v in cols.items()}
     for k in "xyz":
         far[k] = (far[k] * np.float32(1000.0)).astype(np.float32)
@@ -610,12 +613,18 @@ def test_depth_sort_plans_its_passes_from_the_key_range(G):
         far[f"scale_{i}"] = (far[f"scale_{i}"] + np.float32(np.log(1000.0) - 1.5)).astype(np.float32)
     fpacked = G.utils.pack_gaussians(far)
     Rf = G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(fpacked))
+    Rf.sort_passes = 3                                      # a bound learned elsewhere that does not hold here: detected, raised, re-rendered
     fimg = Rf.render(cam).cpu().numpy()
-    assert _ctrl_word(Rf, cam, SORT_PASSES_OFFSET) == 4 and Rf.last_stats["n_visible"] > 1000
+    assert Rf.last_stats["sort_passes"] == 4 and Rf.sort_passes == 4 and Rf.last_stats["n_visible"] > 1000
     foimg, _ = G.orc.render(fpacked, ocam)
     assert_frames_close(fimg, foimg)
-    # the plan is per frame: the near scene on the far scene's workspace geometry goes back to 3 passes
-    assert torch.equal(R.render(cam), torch.from_numpy(img).to("cuda")) and _ctrl_word(R, cam, SORT_PASSES_OFFSET) == 3
+    out = torch.empty_like(img)
+    Rf.sort_passes = 3
+    Rf.enqueue(cam, out=out)                                # enqueue() does not check: the counters do
+    with pytest.raises(_lib.GsrSortPasses):
+        Rf.stats()
+    # the plan is per frame: the near scene goes back to 3 passes whatever the workspace rendered before
+    assert torch.equal(R.render(cam), img) and R.last_stats["sort_passes"] == 3
 
 
 def test_hand_scheduled_blend_walk_equals_the_plain_kernel(G):

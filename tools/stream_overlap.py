@@ -26,7 +26,7 @@ for S in [int(x) for x in os.environ.get("GSR_OVERLAP_SLOTS", "1,2,3,4").split("
     streams = [torch.cuda.Stream() for _ in range(S)]
     outs = [torch.zeros(shape, device="cuda") for _ in range(S)]
     for R in Rs:
-        R.fit_pairs(cam, opts)
+        R.fit_pairs(cam, opts)  # also learns the depth-sort bound
     torch.cuda.synchronize()
     def run(k):
         for f in range(k):

@@ -21,6 +21,7 @@ GSR_ERR_BAD_ARG = -1
 GSR_ERR_WORKSPACE = -2
 GSR_ERR_PAIR_OVERFLOW = -3
 GSR_ERR_HIP = -4
+GSR_ERR_SORT_PASSES = -5
 GSR_MAX_PAIRS = 0xFFFFE000  # include/gsr.h
 
 
@@ -32,6 +33,10 @@ class GsrError(RuntimeError):
 
 class GsrPairOverflow(GsrError):
     pass
+
+
+class GsrSortPasses(GsrError):
+    """The frame's depth keys needed more radix passes than GsrOptions.depth_sort_passes enqueued: the frame is wrong."""
 
 
 class GsrScene(C.Structure):
@@ -74,6 +79,7 @@ class GsrOptions(C.Structure):
         ("blend_impl", C.c_int32),
         ("draw_limit", C.c_int32),
         ("output_dtype", C.c_int32),
+        ("depth_sort_passes", C.c_int32),
     ]
 
 
@@ -84,7 +90,7 @@ class GsrStats(C.Structure):
         ("n_pairs", C.c_uint32),
         ("overflow", C.c_uint32),
         ("max_list_len", C.c_uint32),
-        ("_pad", C.c_uint32),
+        ("sort_passes", C.c_uint32),
         ("wave_entries", C.c_uint64),
         ("fetched_entries", C.c_uint64),
     ]
@@ -149,7 +155,7 @@ def check(rc: int) -> None:
     if rc == GSR_OK:
         return
     msg = (lib.gsr_last_error() or b"").decode("utf-8", "replace")
-    raise (GsrPairOverflow if rc == GSR_ERR_PAIR_OVERFLOW else GsrError)(rc, msg)
+    raise {GSR_ERR_PAIR_OVERFLOW: GsrPairOverflow, GSR_ERR_SORT_PASSES: GsrSortPasses}.get(rc, GsrError)(rc, msg)
 
 
 def default_options() -> GsrOptions:

@@ -86,6 +86,7 @@ static int check_frame(int64_t n, const GsrCamera *cam, const GsrOptions *opts, 
     if (opts->output_dtype != 0 && opts->output_dtype != 1) { set_error("bad output_dtype %d", opts->output_dtype); return GSR_ERR_BAD_ARG; }
     if (opts->blend_impl < 0 || opts->blend_impl > 2) { set_error("bad blend_impl %d", opts->blend_impl); return GSR_ERR_BAD_ARG; }
     if (opts->output_layout < 0 || opts->output_layout > 2) { set_error("bad output_layout %d", opts->output_layout); return GSR_ERR_BAD_ARG; }
+    if (opts->depth_sort_passes < 0 || opts->depth_sort_passes > 4) { set_error("bad depth_sort_passes %d", opts->depth_sort_passes); return GSR_ERR_BAD_ARG; }
     if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) { set_error("workspace must be 256-byte aligned"); return GSR_ERR_BAD_ARG; }
     const size_t need = carve_workspace(workspace, n, cam->width, cam->height, max_pairs, ws);
     if (workspace_bytes < need) {
@@ -243,7 +244,7 @@ int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // depth order: pass 0 drops culled gaussians and leaves V in ctrl; 3 passes on ordinary scenes (sort.hip)
-    rc = launch_depth_sort(ws, rect_fits_8bit(ws), shard_compact(*opts), s);
+    rc = launch_depth_sort(ws, rect_fits_8bit(ws), shard_compact(*opts), opts->depth_sort_passes, s);
     if (rc) return rc;
     // pairs in depth order, stably sorted by tile -> per-tile lists and their ranges; E in ctrl
     return launch_binning(*opts, ws, s);
@@ -340,9 +341,13 @@ int gsr_read_stats(void *workspace, size_t workspace_bytes, GsrStats *out, void 
     }
     GSR_HIP(hipMemcpyAsync(out, workspace, sizeof(GsrStats), hipMemcpyDeviceToHost, s));
     GSR_HIP(hipStreamSynchronize(s));
-    if (out->overflow) {
+    if (out->overflow & 1u) {
         set_error("pair overflow: the frame needs %u (gaussian,tile) pairs", out->n_pairs_bbox);
         return GSR_ERR_PAIR_OVERFLOW;
+    }
+    if (out->overflow & 2u) {
+        set_error("the depth sort needs %u passes, more than depth_sort_passes allowed", out->sort_passes);
+        return GSR_ERR_SORT_PASSES;
     }
     return GSR_OK;
 }

@@ -186,9 +186,9 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(uint32_t *__restrict__ 
     if (tid == 0) {
         const unsigned long long D = grand;
         const uint32_t Dc = D > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)D;
-        if (D > (unsigned long long)max_pairs) { ctrl->batch_overflow = 1u; ctrl->batch_need = max(ctrl->batch_need, Dc); }
-        ctrl->overflow = ctrl->batch_overflow;
-        ctrl->n_pairs_bbox = ctrl->batch_overflow ? max(ctrl->batch_need, Dc) : Dc;
+        if (D > (unsigned long long)max_pairs) { ctrl->batch_overflow |= 1u; ctrl->batch_need = max(ctrl->batch_need, Dc); }
+        ctrl->overflow = ctrl->batch_overflow;  // bit 0: pairs; bit 1: the depth sort was short of passes (sort.hip)
+        ctrl->n_pairs_bbox = (ctrl->batch_overflow & 1u) ? max(ctrl->batch_need, Dc) : Dc;
         ctrl->n_slots = D > (unsigned long long)max_pairs ? max_pairs : (uint32_t)D;
     }
 }

@@ -19,20 +19,20 @@ struct FrameCtrl {
     uint32_t n_pairs;       // E  (pairs that survive footprint culling; written by tile-sort pass 0)
     uint32_t overflow;
     uint32_t max_list_len;
-    uint32_t n_slots;       // min(D, max_pairs): pair slots written by the emit kernel
+    uint32_t sort_passes;   // depth-sort plan of this frame (sort.hip): passes it needs (1..4) — the sorted ids end up in val[sort_passes & 1]
     unsigned long long wave_entries;  // (quadrant, entry) pairs evaluated by the blend   } totals of blend_stats[], filled in
     unsigned long long fetched_entries;  // list entries staged by the blend              } by gsr_read_stats
     uint32_t digit_tot[512]; // per-digit totals of the radix pass in flight
     uint32_t stats_off;      // byte offset of blend_stats[] from this struct, and the number of launch slots the last
     uint32_t stats_slots;    // blend filled (tile_order_kernel writes both; 0 = no blend since the frame was reset)
-    uint32_t sort_passes;    // depth-sort plan of this frame (sort.hip): passes that run (1..4) — the sorted ids end up in
-    uint32_t sort_key_bits;  //   val[sort_passes & 1]; significant bits of key - bits(0.2f); digit width of the passes
-    uint32_t sort_bits_rest; //   after the first.  Written by the pass-0 rowscan.
+    uint32_t n_slots;        // min(D, max_pairs): pair slots written by the emit kernel
+    uint32_t sort_key_bits;  // rest of the depth-sort plan: significant bits of key - bits(0.2f); digit width of the passes
+    uint32_t sort_bits_rest; //   after the first.  Written by the pass-0 rowscan (with sort_passes).
     uint32_t n_cpairs;       // coarse binning: 32x32-cell pairs that survive the sort's drop (count of the coarse ranges pass)
     uint32_t n_records;      // multi-GPU shard: records entering the depth sort (= this rank's visible gaussians; preprocess.hip)
     uint32_t _pad0;
     // ---- everything below survives the per-frame clear ----
-    uint32_t batch_overflow; // sticky across the views of gsr_render_batch
+    uint32_t batch_overflow; // sticky across the views of gsr_render_batch: bit 0 pair overflow, bit 1 depth sort short of passes
     uint32_t batch_need;     // largest D seen in the batch
     uint32_t depth_key_max;  // running maximum of the valid depth keys (pass-0 histogram); consumed and zeroed by the pass-0
                              // rowscan.  Garbage in a fresh workspace only makes the first frame sort over more bits.
@@ -107,8 +107,9 @@ int launch_rasterize_gaussian(int64_t g, const int64_t *bboxes, float *screen, c
                               const float *rgb, float *opacity_buffer, const float *opacity, int W, int H, hipStream_t s);
 
 // Depth order (sort.hip): stable LSD radix sort of the depth keys; leaves V in FrameCtrl.n_visible and the sorted ids (+ packed
-// rects) in val[p] / rect8[p], p = FrameCtrl.sort_passes & 1 (decided on the device from the frame's key range).
-int launch_depth_sort(const Workspace &ws, bool packed_rect, bool compact_input, hipStream_t s);
+// rects) in val[p] / rect8[p], p = FrameCtrl.sort_passes & 1 (decided on the device from the frame's key range).  passes: how
+// many to enqueue (GsrOptions.depth_sort_passes; 0 = 4).
+int launch_depth_sort(const Workspace &ws, bool packed_rect, bool compact_input, int passes, hipStream_t s);
 // Stable radix sort of the pair arrays over key bits [first_bit, key_bits); the first pass drops keys >= drop_from and leaves the
 // survivor count in *n_out.  in_buf / *result_buf: which of pkey[]/pval[] holds input / output.
 int launch_pair_sort(const Workspace &ws, int in_buf, const uint32_t *n_dev, int first_bit, int key_bits, uint32_t drop_from,

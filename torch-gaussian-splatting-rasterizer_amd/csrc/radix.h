@@ -22,6 +22,7 @@ struct PassSpec {
     uint32_t key_base;
     uint32_t drop_from;  // DROP passes discard records with key >= drop_from
     int dyn_pass;
+    int enqueued;        // depth sort: passes the host enqueued (the plan may ask for more: flagged by the pass-0 rowscan)
 };
 
 // The depth sort's keys are the IEEE bits of z_cam >= 0.2 (rasterize.py:377): everything below bits(0.2f) is constant.

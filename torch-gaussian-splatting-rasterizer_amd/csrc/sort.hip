@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t *__restrict
         const uint32_t rest = bits > DEPTH_DIGIT_BITS ? bits - DEPTH_DIGIT_BITS : 0u;
         const uint32_t rest_passes = (rest + DEPTH_DIGIT_BITS - 1) / DEPTH_DIGIT_BITS;
         ctrl->sort_passes = 1u + rest_passes;
+        if (1u + rest_passes > (uint32_t)ps.enqueued) ctrl->batch_overflow |= 2u;  // the caller's bound was too small: the frame is wrong
         ctrl->sort_key_bits = bits;
         ctrl->sort_bits_rest = rest_passes ? (rest + rest_passes - 1) / rest_passes : 0u;
         ctrl->depth_key_max = 0u;  // ready for the next frame's pass-0 histogram (stream-ordered behind this kernel)
@@ -229,9 +230,10 @@ static void launch_pass(const uint32_t *kin, const uint32_t *vin, const uint32_t
 #undef GSR_SCATTER
 }
 
-// Depth order of the gaussians (rasterize.py:424-425).  Always four passes enqueued, 3 run on ordinary scenes (header).
+// Depth order of the gaussians (rasterize.py:424-425).  Four passes enqueued unless the caller bounds them (GsrOptions.
+// depth_sort_passes), 3 run on ordinary scenes (header); a plan that needs more than were enqueued is flagged.
 // Afterwards FrameCtrl.n_visible = V and the sorted ids / packed rects are in val[p] / rect8[p], p = sort_passes & 1.
-int launch_depth_sort(const Workspace &ws, bool packed_rect, bool compact_input, hipStream_t s)
+int launch_depth_sort(const Workspace &ws, bool packed_rect, bool compact_input, int passes, hipStream_t s)
 {
     if (ws.n <= 0) return GSR_OK;
     constexpr int TILE = DEPTH_SORT_THREADS * DEPTH_SORT_ITEMS;
@@ -240,8 +242,9 @@ int launch_depth_sort(const Workspace &ws, bool packed_rect, bool compact_input,
     // compact_input (multi-GPU shard): the input is FrameCtrl.n_records (key, id[, rect]) records in id order, left in
     // key[0] / val[0] / rect8[0] by preprocess.hip, instead of one key per gaussian
     const uint32_t *cnt_dev = compact_input ? &ws.ctrl->n_records : nullptr;
-    for (int p = 0; p < 4; ++p) {
-        const PassSpec ps = {0, 0u, DEPTH_KEY_BASE, KEY_INVALID, p};
+    const int enq = passes >= 1 && passes <= 4 ? passes : 4;
+    for (int p = 0; p < enq; ++p) {
+        const PassSpec ps = {0, 0u, DEPTH_KEY_BASE, KEY_INVALID, p, enq};
         const int in = p & 1, out = in ^ 1;
         const bool first = p == 0;
         if (packed_rect)
@@ -276,7 +279,7 @@ int launch_pair_sort(const Workspace &ws, int in_buf, const uint32_t *n_dev, int
     const uint32_t *cnt_dev = n_dev;
     for (int p = 0; p < passes; ++p) {
         const int shift = first_bit + bits_pp * p;
-        const PassSpec ps = {shift, (1u << std::min(bits_pp, key_bits - shift)) - 1u, 0u, drop_from, -1};
+        const PassSpec ps = {shift, (1u << std::min(bits_pp, key_bits - shift)) - 1u, 0u, drop_from, -1, 0};
         const bool first = p == 0;
         launch_pass<PAIR_SORT_THREADS, PAIR_SORT_ITEMS, false>(ws.pkey[cur], ws.pval[cur], nullptr, ws.pkey[cur ^ 1], ws.pval[cur ^ 1], nullptr, cnt_dev,
                                                  ws.max_pairs, ps, first, false, first ? n_out : nullptr, ws, s);

@@ -83,7 +83,7 @@ def make_camera(qvec, tvec, fx_full: float, fy_full: float, cam_width: int, cam_
 
 def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_row_begin: int = 0, tile_row_step: int = 1,
                  output_layout: int = 0, no_footprint_cull: bool = False, blend_impl: int = 0, draw_limit: int = 0,
-                 output_bf16: bool = False) -> GsrOptions:
+                 output_bf16: bool = False, depth_sort_passes: int = 0) -> GsrOptions:
     o = _lib.default_options()
     o.reference_compat = 1 if reference_compat else 0
     o.early_out_T = float(early_out_T)
@@ -94,6 +94,7 @@ def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_r
     o.blend_impl = int(blend_impl)
     o.draw_limit = int(draw_limit)
     o.output_dtype = 1 if output_bf16 else 0  # frame stored as bfloat16; accumulation stays fp32
+    o.depth_sort_passes = int(depth_sort_passes)  # 0: no bound (a Rasterizer fills in what it has learned from its frames' counters)
     return o
 
 
@@ -108,6 +109,9 @@ class Rasterizer:
     def __init__(self, scene: GaussianScene, max_pairs: Optional[int] = None):
         self.scene = scene
         self.max_pairs = min(_lib.GSR_MAX_PAIRS, int(max_pairs) if max_pairs else max(1 << 20, 8 * scene.n))
+        # radix passes the depth sort of this scene's frames has needed so far (GsrStats.sort_passes, learned whenever the counters
+        # are read): passed as GsrOptions.depth_sort_passes so that the passes a frame does not need are not even enqueued
+        self.sort_passes = 0
         self._ws: Optional[torch.Tensor] = None
         self._rendered = True
         self._ws_key = None
@@ -135,11 +139,20 @@ class Rasterizer:
         rows = shard_rows(cam.height, opts.tile_row_begin, opts.tile_row_step) * TILE
         return (rows, cam.width, 3), (rows, cam.width)
 
+    def _bounded(self, opts: GsrOptions) -> GsrOptions:
+        """opts with the learned depth-sort bound filled in (a copy), unless the caller set one."""
+        if opts.depth_sort_passes != 0 or self.sort_passes == 0:
+            return opts
+        o = GsrOptions.from_buffer_copy(opts)
+        o.depth_sort_passes = self.sort_passes
+        return o
+
     # -- one frame ------------------------------------------------------------------------------
     def enqueue(self, cam: GsrCamera, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None,
                 final_T: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Enqueue one frame on the current stream; no host synchronisation, no overflow check."""
-        opts = opts or make_options()
+        """Enqueue one frame on the current stream; no host synchronisation, no check of the two caller-supplied bounds
+        (max_pairs, the depth-sort passes learned so far): stats() / render() report a frame that exceeded either."""
+        opts = self._bounded(opts or make_options())
         ws = self._workspace(cam.width, cam.height)
         shape, _ = self._out_shape(cam, opts)
         dtype = torch.bfloat16 if opts.output_dtype == 1 else torch.float32
@@ -167,6 +180,7 @@ class Rasterizer:
         st = GsrStats()
         rc = lib.gsr_read_stats(self._ws.data_ptr(), self._ws.numel(), C.byref(st), _stream_ptr(self.scene.device))
         self.last_stats = st.as_dict()
+        self.sort_passes = max(self.sort_passes, int(st.sort_passes))  # also when the frame was short of passes: the retry has them
         check(rc)
         return self.last_stats
 
@@ -188,6 +202,10 @@ class Rasterizer:
                     raise
                 self.max_pairs = int(min(_lib.GSR_MAX_PAIRS, need + need // 8 + 1024))
                 continue
+            except _lib.GsrSortPasses:
+                if opts.depth_sort_passes != 0:
+                    raise  # the caller's own bound
+                continue   # stats() has raised the learned bound
             return (img, final_T) if return_T else img
 
     def render_batch(self, cams, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -209,7 +227,7 @@ class Rasterizer:
             ws = self._workspace(W, H)
             # overflow is only visible per view: check every view's counters cheaply by rendering view by view
             # when the batch is small, else trust fit_pairs() and check the last one
-            check(lib.gsr_render_batch(C.byref(sc), arr, len(cams), C.byref(opts), self.max_pairs, ws.data_ptr(), ws.numel(),
+            check(lib.gsr_render_batch(C.byref(sc), arr, len(cams), C.byref(self._bounded(opts)), self.max_pairs, ws.data_ptr(), ws.numel(),
                                        out.data_ptr(), H * W * 3, _stream_ptr(self.scene.device)))
             try:
                 self.stats()
@@ -217,6 +235,9 @@ class Rasterizer:
             except _lib.GsrPairOverflow:
                 need = int(self.last_stats["n_pairs_bbox"])
                 self.max_pairs = int(min(_lib.GSR_MAX_PAIRS, need + need // 4 + 1024))
+            except _lib.GsrSortPasses:
+                if opts.depth_sort_passes != 0:
+                    raise
 
     def fit_pairs(self, cam: GsrCamera, opts: Optional[GsrOptions] = None, slack: float = 1.25) -> int:
         """Size the pair buffers to this view: one probing frame, then max_pairs = slack * D (+ margin).
@@ -278,6 +299,11 @@ class FramesInFlight:
         for r in self.rasterizers:
             r.max_pairs = int(max_pairs)
 
+    def set_sort_passes(self, passes: int) -> None:
+        """Share the depth-sort bound one slot has learned (Rasterizer.sort_passes) with all of them."""
+        for r in self.rasterizers:
+            r.sort_passes = max(r.sort_passes, int(passes))
+
     def submit(self, cam: GsrCamera, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None,
                slot: Optional[int] = None) -> int:
         """Enqueue one frame on the next slot's stream (round robin) and return the slot."""
@@ -313,21 +339,27 @@ class FramesInFlight:
                 st.wait_stream(cur)  # `out` (and the workspaces) may have been allocated / used on the current stream
             ws_arr = (C.c_void_p * n)(*[w.data_ptr() for w in wss])
             st_arr = (C.c_void_p * n)(*[int(st.cuda_stream) for st in self.streams])
-            check(lib.gsr_render_batch_slots(C.byref(sc), arr, len(cams), C.byref(opts), self.rasterizers[0].max_pairs, ws_arr,
-                                             wss[0].numel(), st_arr, n, out.data_ptr(), H * W * 3))
+            self.set_sort_passes(max(r.sort_passes for r in self.rasterizers))
+            check(lib.gsr_render_batch_slots(C.byref(sc), arr, len(cams), C.byref(self.rasterizers[0]._bounded(opts)),
+                                             self.rasterizers[0].max_pairs, ws_arr, wss[0].numel(), st_arr, n, out.data_ptr(), H * W * 3))
             for r in self.rasterizers:
                 r._rendered = True
-            need = 0
+            need, short = 0, False
             for k in range(min(n, len(cams))):
                 try:
                     self.stats(k)
                 except _lib.GsrPairOverflow:
                     need = max(need, int(self.rasterizers[k].last_stats["n_pairs_bbox"]))
+                except _lib.GsrSortPasses:
+                    if opts.depth_sort_passes != 0:
+                        raise
+                    short = True  # stats() has raised that slot's learned bound; the re-run shares it
             for k in range(n):
                 self.wait(k)
-            if need == 0:
+            if need == 0 and not short:
                 return out
-            self.set_max_pairs(int(min(_lib.GSR_MAX_PAIRS, need + need // 4 + 1024)))
+            if need:
+                self.set_max_pairs(int(min(_lib.GSR_MAX_PAIRS, need + need // 4 + 1024)))
 
     def wait(self, slot: int) -> None:
         torch.cuda.current_stream(self.scene.device).wait_stream(self.streams[slot])
