@@ -366,8 +366,11 @@ def main():
             "algorithmic_bytes_per_launch": blend_bytes, "avg_kernel_ms": stage[2],
             "limiter": "on-chip: VALU issue + LDS reads (exact per-pixel evaluation: ~70 flop and 6.4 exp per algorithmic byte, "
                        "SURVEY.md §7 hard part 1); HBM is not the bound, frac is the contract figure",
-            "note": "traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction, an upper bound for gathered 48-B records) + WRITE_SIZE, "
-                    "separate --pmc passes, from profiles/",
+            "note": "avg_kernel_ms: HIP events around the stage on ONE stream, one frame in flight (profiles/r2_kernel_stats.csv, collected "
+                    "with --frames-in-flight 1, agrees); in the timed loop kernels of the frames in flight share the machine and "
+                    "their individual durations stretch (profiles/r2_kernel_stats_frames_in_flight.csv: the same kernel averages "
+                    "0.60 ms there).  traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction, an upper bound for gathered 48-B "
+                    "records) + WRITE_SIZE, separate --pmc passes, from profiles/",
         }
         # honesty figures: pixel evaluations, and the two pipes that bound the kernel, priced from the committed
         # counters: VALU wave-instructions per launch at one fp32 issue per 2 cycles per SIMD (1024 SIMDs), LDS-array cycles per
