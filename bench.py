@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--workload", default="bicycle", choices=sorted(WORKLOADS))
     ap.add_argument("--gaussians", type=int, default=0, help="override the gaussian count (0 = the workload's)")
     ap.add_argument("--early-out-T", type=float, default=0.0)
-    ap.add_argument("--blend-impl", type=int, default=0, help="0 default blend, 1 the same with its walk in plain C, 2 experimental matrix-pipe blend")
+    ap.add_argument("--blend-impl", type=int, default=0, help="0 default blend, 1 the same with its walk in plain C")
     ap.add_argument("--sh-half", action="store_true", help="headline with SH coefficients stored as fp16 (default: fp32, the reference's type)")
     ap.add_argument("--bf16-output", action="store_true", help="headline with the frame stored as bfloat16; accumulation stays fp32")
     ap.add_argument("--camera", type=int, default=0)
@@ -135,6 +135,7 @@ def timed_frames(R, cams, opts, out, steps, warmup, dev, slots=1):
     fif = renderer.FramesInFlight(R.scene, slots=slots, max_pairs=R.max_pairs)
     fif.rasterizers[0] = R
     fif.set_sort_passes(R.sort_passes)
+    opts = R.bounded(opts)  # the depth-sort bound the probing frames have learned; fif.stats() below speaks for EVERY frame of a slot
     outs = [out] + [torch.empty_like(out) for _ in range(slots - 1)]
     for i in range(warmup):
         fif.submit(cams[i % len(cams)], opts, out=outs[i % slots], slot=i % slots)
@@ -143,7 +144,10 @@ def timed_frames(R, cams, opts, out, steps, warmup, dev, slots=1):
     for i in range(steps):
         fif.submit(cams[i % len(cams)], opts, out=outs[i % slots], slot=i % slots)
     torch.cuda.synchronize(dev)
-    return time.perf_counter() - t0
+    el = time.perf_counter() - t0
+    for k in range(slots):
+        fif.stats(k)  # raises if ANY frame of the slot exceeded max_pairs or the depth-sort bound (GsrOptions.keep_flags chain)
+    return el
 
 
 def psnr_pair(img, ref):
@@ -239,6 +243,8 @@ def main():
     need = max(R.fit_pairs(c, opts) for c in cams)
     fif.set_max_pairs(need)
     fif.set_sort_passes(R.sort_passes)  # the depth-sort bound learned from the views' counters (GsrOptions.depth_sort_passes)
+    opts = R.bounded(opts)  # passed explicitly: enqueue() / submit() apply no bound of their own; every slot's stats() after the timed
+    # region speaks for ALL its frames (they are chained with GsrOptions.keep_flags)
     R.render(cam, opts, out=strip_view)
     shard_stats = dict(R.last_stats)
     torch.cuda.synchronize(dev)
@@ -270,7 +276,7 @@ def main():
     elapsed, frame = timed_region(step, drain, args.steps, args.warmup)
     for k in range(S):
         if fif.rasterizers[k]._ws is not None:
-            fif.stats(k)  # raises if the slot's last frame overflowed
+            fif.stats(k)  # raises if ANY of the slot's frames exceeded max_pairs or the depth-sort bound
     # the same loop with ONE frame in flight (one stream, one workspace): the per-frame latency figure
     single = None
     if S > 1:
@@ -313,7 +319,7 @@ def main():
                        "sharding": f"tile rows interleaved over {world} GPU(s), RCCL gather to rank 0" if world > 1 else "none",
                        "reference_compat": True, "early_out_T": args.early_out_T, "depth_sort_passes": R.sort_passes, "sh_storage": "f16" if args.sh_half else "f32",
                        "frame_storage": "bf16 (fp32 accumulation)" if args.bf16_output else "f32",
-                       "blend_impl": {0: "valu", 1: "valu, plain-C walk", 2: "mfma (experimental)"}.get(args.blend_impl, str(args.blend_impl))},
+                       "blend_impl": {0: "valu", 1: "valu, plain-C walk"}.get(args.blend_impl, str(args.blend_impl))},
             "stats_rank0_shard": shard_stats,
         }
         result["config"]["frames_in_flight"] = S

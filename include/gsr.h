@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 300 /* 0.3.0: GsrOptions.depth_sort_passes, GsrStats.sort_passes, GSR_ERR_SORT_PASSES.  0.2.1: + gsr_render_batch_slots.
+#define GSR_VERSION 400 /* 0.4.0: GsrOptions.keep_flags; GsrStats.sort_passes reports the worst frame when the bound was exceeded; blend_impl 2
+                            (matrix-pipe experiment) removed; the frame clear covers every word of the control block.  0.3.0: GsrOptions.depth_sort_passes, GsrStats.sort_passes, GSR_ERR_SORT_PASSES.  0.2.1: + gsr_render_batch_slots.
                             0.2.0: gsr_preprocess_geometry/_color removed (measured slower), gsr_read_stats takes a non-const workspace */
 
 typedef enum GsrStatus {
@@ -93,10 +94,7 @@ typedef struct GsrOptions {
                                  reference's full 3-sigma tile rect — only to prove that property in tests. */
     int32_t blend_impl;       /* 0 (default): the blend kernel with its inner walk hand-scheduled (EXEC-masked update, csrc/blend.hip).
                                  1: the same kernel with the walk in plain C — the readable statement of the arithmetic and the A/B
-                                 reference; frames are bit-identical to 0.
-                                 2: EXPERIMENTAL, not the product path: quadratic evaluated on the matrix pipe
-                                 (v_mfma_f32_32x32x2_f32) as [gaussian coefficients] x [pixel basis]; same frame within ~1e-5 absolute
-                                 in the exponent (125 dB vs the oracle), not faster (see blend_mfma.hip). */
+                                 reference; frames are bit-identical to 0. */
     int32_t draw_limit;       /* 0 (default): blend everything.  k > 0: blend only the first k gaussians of the reference's
                                  draw order (depth order restricted to those its skip guard rasterize.py:441 lets through) —
                                  the progressive frames of --generate_video (rasterize.py:448-450). */
@@ -109,6 +107,11 @@ typedef struct GsrOptions {
                                  what the frames need — GsrStats.sort_passes of an earlier frame of the scene (3 whenever the depths stay
                                  within 0.2 .. 13 000): only that many are enqueued.  Verified on the device like max_pairs: a frame
                                  that needs more is flagged and gsr_read_stats returns GSR_ERR_SORT_PASSES. */
+    int32_t keep_flags;       /* 0 (default): the frame starts from a cleared control block (a fresh workspace needs no initialisation).
+                                 1: the frame keeps the overflow record of the frames rendered before it on this workspace (bits of
+                                 GsrStats.overflow, the largest D, the most depth-sort passes), so ONE gsr_read_stats after a run of
+                                 unchecked frames — first frame 0, the rest 1 — reports whether ANY of them exceeded max_pairs or
+                                 depth_sort_passes.  The views of gsr_render_batch are chained this way internally. */
 } GsrOptions;
 
 /* Counters of one frame (device -> host with gsr_read_stats). */
@@ -120,7 +123,8 @@ typedef struct GsrStats {
     uint32_t overflow;      /* bit 0: D exceeded max_pairs (frame incomplete); bit 1: the depth sort needed more passes than
                                depth_sort_passes allowed (frame wrong) */
     uint32_t max_list_len;  /* longest per-tile list */
-    uint32_t sort_passes;   /* radix passes the depth sort of this frame needs (1..4): the bound to pass as depth_sort_passes */
+    uint32_t sort_passes;   /* radix passes the depth sort of this frame needs (1..4): the bound to pass as depth_sort_passes.  When
+                               overflow bit 1 is set: the most any frame since the last cleared one (keep_flags, batches) needed */
     uint64_t wave_entries;  /* (8x8 quadrant, entry) pairs the blend actually evaluated: 64 pixel evaluations each */
     uint64_t fetched_entries; /* list entries the blend staged (<= n_pairs: a saturated tile stops fetching) */
 } GsrStats;
@@ -181,7 +185,7 @@ int gsr_render_forward(const GsrScene *scene, const GsrCamera *cam, const GsrOpt
 /* Several views of ONE resident scene, enqueued back to back on the stream with one workspace (the reference renders
  * one view per process, rasterize.py:315-329).  cams[n_cams] [host] must share width/height; frame i goes to
  * out_images + i * frame_stride (in elements of the output dtype).  Counters afterwards describe the LAST view; an overflow in any view is
- * sticky in them. */
+ * sticky in them, and n_pairs_bbox / sort_passes then report what the WORST view needed (the values to re-render with). */
 int gsr_render_batch(const GsrScene *scene, const GsrCamera *cams /* [host] */, int32_t n_cams, const GsrOptions *opts,
                      int64_t max_pairs, void *workspace, size_t workspace_bytes, void *out_images, int64_t frame_stride,
                      void *stream);

@@ -6,8 +6,9 @@
                                                                                  coefficients >= 100 dB; + bf16 frame store >= 55 dB
   configs[4]  uniform_box        20 000 000 gaussians, 3840x2160                 frame >= 100 dB; footprint culling off and 8-shard
                                                                                  reassembly bit-identical at that size
-  configs[3]  (8-GPU tile-row shard + RCCL gather of configs[2]): tools/dist_check.py under torchrun, nccl when the box has
-              >= 2 GPUs, otherwise the same ranks over gloo sharing the one GPU (the sharding / gather / assembly logic is the same).
+  configs[3]  bicycle stand-in, the whole 25-camera set, 8 interleaved tile-row shards per frame on this GPU, assembled and compared
+              bit for bit with the unsharded frames (+ 3 cameras vs the oracle); the gather: tools/dist_check.py under torchrun,
+              nccl when the box has >= 2 GPUs, otherwise the same ranks over gloo sharing the one GPU.
 
 The real MipNeRF-360 scenes are not available offline: these are the seeded stand-ins of SURVEY.md §8(d).
 Tolerance stated by north_star: PSNR >= 50 dB vs the torch reference; held here: >= 100 dB (fp32), >= 55 dB (bf16 store).
@@ -156,6 +157,84 @@ def test_configs4_box_4k_exactness_properties(G, box4k):
         k = len(range(r, tiles_y, 8))
         out.view(tiles_y, 16, cam.width, 3)[r::8] = strip[: k * 16].view(k, 16, cam.width, 3)
     assert torch.equal(out, full)
+
+
+def test_configs3_bicycle_camera_set_in_8_tile_row_shards(G):
+    """configs[3] at its own workload, on one GPU: the bicycle stand-in (6 131 954 gaussians) at 1920x1080 over the WHOLE
+    25-camera set, every frame rendered as the 8 interleaved tile-row shards an 8-GPU node would render (rank r = tile rows
+    r, r+8, ...; the rank's loop is bench.py's: frames in flight on separate streams, strips into padded wire buffers,
+    bounds learned on camera 0 and passed explicitly, ONE stats() per slot after the run) and put together by
+    TileRowPlan.assemble (what rank 0 does after the RCCL gather).
+      (i)   every camera's assembled frame is bit-identical to its unsharded frame;
+      (ii)  three cameras spread over the ring are checked against the CPU oracle at full size (>= 100 dB);
+      (iii) the pair-buffer / depth-sort bounds learned on camera 0 hold for the other cameras or are re-learned: a camera
+            that exceeds one is reported by the slot's stats() (the frames are chained with GsrOptions.keep_flags) and the
+            rank re-renders with room for it — never a silently incomplete frame.
+    The gather itself (gloo here, RCCL on a multi-GPU box) is test_configs3_sharded_frame_over_*."""
+    from gsr_amd import _lib
+    from gsr_amd import dist as gdist
+
+    W, H, NCAM, GPUS = 1920, 1080, 25, 8
+    packed = G.utils.pack_gaussians(G.synthetic.mip360_like(6_131_954, 361))
+    scene = G.renderer.GaussianScene.from_packed(packed)
+    views = [_ring_camera(G, W, H, i) for i in range(NCAM)]
+    cams = [v[0] for v in views]
+    mk = G.renderer.make_options
+
+    R = G.renderer.Rasterizer(scene)
+    R.fit_pairs(cams[0])
+    learned0 = (R.max_pairs, R.sort_passes)
+    full = [R.render(c) for c in cams]            # render() verifies every frame and re-learns a bound that does not hold
+    print(f"\nunsharded: bounds learned on camera 0 {learned0}, after the set {(R.max_pairs, R.sort_passes)}")
+    del R
+
+    plan = gdist.TileRowPlan(H, W, GPUS)
+    relearned = []
+    # every frame's wire buffer (strip padded to the longest rank's rows), allocated and zeroed BEFORE any slot stream writes
+    # into it: FramesInFlight leaves the ordering of output buffers to the caller
+    wire = torch.zeros((GPUS, NCAM) + tuple(plan.padded_shape()), device="cuda")
+    torch.cuda.synchronize()
+    for r in range(GPUS):
+        so = plan.shard_options(r)
+        rows = len(plan.rows[r]) * 16
+        fif = G.renderer.FramesInFlight(scene, slots=2)
+        r0 = fif.rasterizers[0]
+        r0.fit_pairs(cams[0], mk(**so))
+        fif.set_max_pairs(r0.max_pairs)
+        fif.set_sort_passes(r0.sort_passes)
+        for attempt in range(5):
+            opts = r0.bounded(mk(**so))
+            for i, c in enumerate(cams):
+                fif.submit(c, opts, out=wire[r, i, :rows])
+            need, passes = 0, 0
+            for k in range(fif.slots):
+                try:
+                    fif.stats(k)
+                except _lib.GsrPairOverflow:
+                    need = max(need, fif.rasterizers[k].last_stats["n_pairs_bbox"])
+                except _lib.GsrSortPasses:
+                    passes = max(passes, fif.rasterizers[k].last_stats["sort_passes"])
+            if not need and not passes:
+                break
+            relearned.append((r, attempt, need, passes))
+            if need:
+                fif.set_max_pairs(need + need // 8 + 1024)
+            if passes:
+                fif.set_sort_passes(passes)
+        else:
+            pytest.fail(f"rank {r}: bounds still exceeded after 5 runs: {relearned}")
+        fif.synchronize()
+        del fif, r0
+    print(f"shard runs that re-learned a bound (rank, attempt, pairs needed, passes needed): {relearned}")
+    for i in range(NCAM):
+        frame = plan.assemble([wire[r][i] for r in range(GPUS)])
+        assert torch.equal(frame, full[i]), f"camera {i}: the 8-shard frame differs from the unsharded one"
+    del wire
+    for i in (0, 8, 17):
+        oimg, _, _ = _oracle_frame(G, packed, views[i][1])
+        img = full[i].cpu().numpy()
+        assert_frames_close(img, oimg)
+        print(f"camera {i}: {psnr(img, oimg):.1f} dB vs oracle")
 
 
 def _run_dist_check(backend, ranks, extra_env=None, timeout=600):

@@ -131,6 +131,46 @@ def test_run_rasterization_cli_reproduces_the_reference_frame(mods, tmp_path):
         mods.rasterize.render_scene(scene_dir, model_dir, 0, 2)
 
 
+def test_run_rasterization_cli_scale_factor_4(mods, tmp_path):
+    """BASELINE configs[0] as worded ("scale-factor 4") on fixture f3b: the reference's own run with --scale-factor 4 over
+    images_4/ (image_id 42, a tilted camera, a 150x93 frame that is no multiple of 16).  Quirk Q3: the EWA focal stays
+    full-res fx / 2 whatever the scale factor (rasterize.py:216), so splats are 2x too wide for this frame — that IS the
+    reference image, and the CLI must reproduce it (rasterize.py:333-345)."""
+    from click.testing import CliRunner
+    from PIL import Image
+
+    g = load_golden("f3_edge.npz")
+    assert int(g["b_scale_factor"]) == 4 and int(g["b_image_id"]) == 42
+    root = str(tmp_path)
+    W, H = int(g["width"]), int(g["height"])
+    sparse = os.path.join(root, "scene", "sparse", "0")
+    os.makedirs(sparse)
+    mods.colmap.write_intrinsics_binary(os.path.join(sparse, "cameras.bin"), [mods.colmap.Camera(
+        id=1, model="PINHOLE", width=int(g["cam_width"]), height=int(g["cam_height"]),
+        params=np.array([float(g["fx_full"]), float(g["fy_full"]), int(g["cam_width"]) / 2, int(g["cam_height"]) / 2]))])
+    poses = [mods.synthetic.Pose(int(g["a_image_id"]), g["a_qvec"], g["a_tvec"], "edge_a.png"),
+             mods.synthetic.Pose(int(g["b_image_id"]), g["b_qvec"], g["b_tvec"], "edge_b.png")]
+    mods.colmap.write_extrinsics_binary(os.path.join(sparse, "images.bin"), poses)
+    os.makedirs(os.path.join(root, "scene", "images_4"))
+    for p in poses:
+        Image.new("RGB", (W, H)).save(os.path.join(root, "scene", "images_4", p.name))
+    model = os.path.join(root, "model", "point_cloud", "iteration_30000")
+    os.makedirs(model)
+    mods.ply.write_gaussians_ply(os.path.join(model, "point_cloud.ply"), golden_columns(g))
+    out_dir = str(tmp_path / "out")
+    res = CliRunner().invoke(mods.rasterize.run_rasterization, [
+        "--input_dir", os.path.join(root, "scene"), "--trained_model_path", os.path.join(root, "model"), "--output_path", out_dir,
+        "--scene-index", "42", "--scale-factor", "4"], catch_exceptions=False)
+    assert res.exit_code == 0, res.output
+    img = np.load(os.path.join(out_dir, "render.npy"))
+    assert img.shape == (H, W, 3)
+    assert psnr(img, g["b_image"]) >= 100.0
+    assert_frames_close(img, g["b_image"])
+    # the same files with --scale-factor 2 have no images_2/ directory: the reference fails on the missing image too
+    with pytest.raises(FileNotFoundError):
+        mods.rasterize.render_scene(os.path.join(root, "scene"), os.path.join(root, "model"), 42, 2)
+
+
 def test_generate_video_writes_the_reference_frame_sequence(mods, tmp_path):
     from click.testing import CliRunner
     from PIL import Image

@@ -58,18 +58,13 @@ def main():
     if a.ab_rounds:
         for _ in range(a.ab_rounds):
             time_blend("exact, valu", mk(), mk())
-            time_blend("exact, mfma", mk(), mk(blend_impl=2))
             time_blend("early_out_T=1e-4, valu", mk(), mk(early_out_T=1e-4))
-            time_blend("early_out_T=1e-4, mfma", mk(), mk(early_out_T=1e-4, blend_impl=2))
         return
     time_blend("exact", mk(), mk())
     for T in (1e-6, 1e-4, 1e-2, 0.5):
         time_blend(f"early_out_T={T:g}", mk(), mk(early_out_T=T))
     time_blend("early_out_T=2 (first chunk only)", mk(), mk(early_out_T=2.0))
     time_blend("draw_limit=1 (near-empty lists)", mk(draw_limit=1), mk(draw_limit=1))
-    for impl in (2,):
-        time_blend("exact, mfma", mk(), mk(blend_impl=impl))
-        time_blend("early_out_T=1e-4, mfma", mk(), mk(early_out_T=1e-4, blend_impl=impl))
 
 
 if __name__ == "__main__":

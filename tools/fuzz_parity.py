@@ -17,6 +17,40 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 
 
+def build_case(case_seed, max_n=60000):
+    """The deterministic scene / frame / camera of one campaign case (also used by tests/ to replay a case by its seed).
+    Returns the rng too: the campaign keeps drawing its per-case options from it."""
+    from gsr_amd import synthetic, utils
+
+    rng = np.random.default_rng(case_seed)
+    n = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, int(rng.integers(1, max_n))]))
+    W = int(rng.choice([1, 15, 16, 17, 31, 33, 160, 333, 640, int(rng.integers(1, 1300))]))
+    H = int(rng.choice([1, 15, 16, 17, 96, 197, 360, int(rng.integers(1, 800))]))
+    gen = synthetic.mip360_like if rng.random() < 0.7 else synthetic.uniform_box
+    cols = gen(n, int(rng.integers(0, 1 << 30)))
+    shift = float(rng.choice([0.0, 1.0, 2.0, 3.5]))
+    for i in range(3):
+        cols[f"scale_{i}"] = (cols[f"scale_{i}"] + np.float32(shift)).astype(np.float32)
+    if rng.random() < 0.2:  # stacks of exactly equal depth
+        k = int(rng.integers(1, 50))
+        for c in "xyz":
+            cols[c] = np.ascontiguousarray(cols[c][np.arange(n) % k])
+    if rng.random() < 0.2:
+        cols["opacity"] = np.full_like(cols["opacity"], float(rng.choice([-8.0, 6.0, 12.0])))
+    if gen is synthetic.uniform_box:
+        pose = synthetic.box_camera()
+    else:
+        th = rng.uniform(0, 2 * np.pi)
+        rad = float(rng.choice([0.5, 2.0, 4.0, 30.0]))
+        pose = synthetic.look_at_pose((rad * np.cos(th), rad * np.sin(th), rng.uniform(-1, 2)), (0, 0, 0), 1, "c.png")
+    fx = synthetic.pinhole_focal(max(W, 2), float(rng.choice([30.0, 60.0, 100.0])))
+    sf = int(rng.choice([1, 2, 4]))
+    args = (pose.qvec, pose.tvec, sf * fx, sf * fx, sf * W, sf * H, W, H)
+    degree = int(rng.choice([3, 3, 3, 0, 1, 2]))
+    return dict(rng=rng, n=n, W=W, H=H, gen=gen, shift=shift, degree=degree, pose=pose, args=args, sf=sf,
+                packed=utils.pack_gaussians(cols))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
@@ -52,34 +86,12 @@ def main():
     mk = renderer.make_options
     while time.time() < t_end and not (a.case_seed is not None and cases):
         case_seed = int(master.integers(0, 1 << 62)) if a.case_seed is None else a.case_seed
-        rng = np.random.default_rng(case_seed)
-        n = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, int(rng.integers(1, a.max_n))]))
-        W = int(rng.choice([1, 15, 16, 17, 31, 33, 160, 333, 640, int(rng.integers(1, 1300))]))
-        H = int(rng.choice([1, 15, 16, 17, 96, 197, 360, int(rng.integers(1, 800))]))
-        gen = synthetic.mip360_like if rng.random() < 0.7 else synthetic.uniform_box
-        cols = gen(n, int(rng.integers(0, 1 << 30)))
-        shift = float(rng.choice([0.0, 1.0, 2.0, 3.5]))
-        for i in range(3):
-            cols[f"scale_{i}"] = (cols[f"scale_{i}"] + np.float32(shift)).astype(np.float32)
-        if rng.random() < 0.2:  # stacks of exactly equal depth
-            k = int(rng.integers(1, 50))
-            for c in "xyz":
-                cols[c] = np.ascontiguousarray(cols[c][np.arange(n) % k])
-        if rng.random() < 0.2:
-            cols["opacity"] = np.full_like(cols["opacity"], float(rng.choice([-8.0, 6.0, 12.0])))
-        if gen is synthetic.uniform_box:
-            pose = synthetic.box_camera()
-        else:
-            th = rng.uniform(0, 2 * np.pi)
-            rad = float(rng.choice([0.5, 2.0, 4.0, 30.0]))
-            pose = synthetic.look_at_pose((rad * np.cos(th), rad * np.sin(th), rng.uniform(-1, 2)), (0, 0, 0), 1, "c.png")
-        fx = synthetic.pinhole_focal(max(W, 2), float(rng.choice([30.0, 60.0, 100.0])))
-        sf = int(rng.choice([1, 2, 4]))
-        args = (pose.qvec, pose.tvec, sf * fx, sf * fx, sf * W, sf * H, W, H)
+        c = build_case(case_seed, a.max_n)
+        rng, n, W, H, gen, shift, degree, pose, args, packed = (c[k] for k in ("rng", "n", "W", "H", "gen", "shift", "degree", "pose", "args", "packed"))
         cam, ocam = renderer.make_camera(*args), orc.camera(*args)
-        degree = int(rng.choice([3, 3, 3, 0, 1, 2]))
-        packed = utils.pack_gaussians(cols)
-        desc = f"case-seed={case_seed} n={n} {W}x{H} gen={gen.__name__} shift={shift} deg={degree} sf={sf}"
+        desc = f"case-seed={case_seed} n={n} {W}x{H} gen={gen.__name__} shift={shift} deg={degree} sf={c['sf']}"
+        # the case names itself BEFORE it runs: a stall (the harness kills a silent run) then points at its case
+        print(f"case {cases}: {desc}", flush=True)
         try:
             scene = renderer.GaussianScene.from_packed(packed, sh_degree=degree) if degree != 3 else renderer.GaussianScene.from_packed(packed)
             R = renderer.Rasterizer(scene, max_pairs=int(rng.choice([0, 1000])) or None)
@@ -118,16 +130,6 @@ def main():
                 if rows:
                     full.view(tiles_y, 16, W, 3)[r::step] = strip.view(len(rows), 16, W, 3)
             assert torch.equal(full[:H], img), f"shards (step {step}) differ"
-            m = R.render(cam, mk(blend_impl=2)).cpu().numpy()
-            if a.case_seed is not None:
-                dm = np.abs(m.astype(np.float64) - oimg).max(2)
-                print(f"matrix-pipe blend: pixels off by > 1e-5: {(dm > 1e-5).sum()}; > 4.5e-3: {(dm > 4.5e-3).sum()}; worst {dm.max():.6f}; stats {R.last_stats}")
-                for y, x in zip(*np.unravel_index(np.argsort(-dm, axis=None)[:8], dm.shape)):
-                    print(f"   pixel ({x},{y}) tile ({x // 16},{y // 16}) in-tile ({x % 16},{y % 16}) diff {dm[y, x]:.6f}  T oracle {oT[y, x]:.3e}")
-            try:
-                close(m, oimg)
-            except AssertionError as e:
-                raise AssertionError(f"matrix-pipe blend: {e}") from None
             # -- the other modes, each against an exact property or the oracle ----------------------------------
             assert torch.equal(R.render(cam, mk(output_layout=1)), img.transpose(0, 1)), "layout 1 is not the transpose"
             nc = R.render(cam, mk(reference_compat=False))

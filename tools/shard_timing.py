@@ -44,6 +44,7 @@ for G in (1, 2, 4, 8) if only is None else (only[0],):
         fif.set_max_pairs(fif.rasterizers[0].fit_pairs(cam, opts))
         outs = [torch.zeros(shape, device="cuda") for _ in range(SLOTS)]
         fif.set_sort_passes(fif.rasterizers[0].sort_passes)  # the depth-sort bound learned by the probing frame
+        opts = fif.rasterizers[0].bounded(opts)
         single = renderer.FramesInFlight(scene, slots=1, max_pairs=fif.rasterizers[0].max_pairs)
         single.set_sort_passes(fif.rasterizers[0].sort_passes)
         timed(single, opts, outs[:1], 6)  # warm the clocks before the first measurement of the process

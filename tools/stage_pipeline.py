@@ -36,7 +36,12 @@ for NW in [int(x) for x in (sys.argv[1:] or ["2", "3", "4"])]:
             return torch.cuda.ExternalStream(st.value)
         A, B = masked(lambda r: r < split), masked(lambda r: r >= split)
     else:
-        A, B = torch.cuda.Stream(), torch.cuda.Stream()
+        # GSR_PRIO=1: stream A (preprocess + sorts: HBM- and latency-bound, short workgroups) at HIGH priority, the blend at normal
+        # priority: A's workgroups take the slots the blend's workgroups free, the blend's resident ones keep computing
+        prio = int(os.environ.get("GSR_PRIO", "0"))
+        lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+        A = torch.cuda.Stream(priority=-1 if prio == 1 else (0 if prio == 0 else 0))
+        B = torch.cuda.Stream(priority=-1 if prio == 2 else 0)
     sorted_ev = [torch.cuda.Event() for _ in range(NW)]
     blended_ev = [torch.cuda.Event() for _ in range(NW)]
     torch.cuda.synchronize()
@@ -58,4 +63,4 @@ for NW in [int(x) for x in (sys.argv[1:] or ["2", "3", "4"])]:
     K = 60
     t0 = time.perf_counter(); run(K); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
     ref = R0.render(cam, opts)
-    print(f"stage pipeline, CU split {split}/8, {NW} workspaces: {dt * 1e3:.3f} ms per frame ({1 / dt:.0f} frames/s)  frames identical: {all(torch.equal(o, ref) for o in outs)}", flush=True)
+    print(f"stage pipeline, prio {os.environ.get('GSR_PRIO', '0')}, CU split {split}/8, {NW} workspaces: {dt * 1e3:.3f} ms per frame ({1 / dt:.0f} frames/s)  frames identical: {all(torch.equal(o, ref) for o in outs)}", flush=True)

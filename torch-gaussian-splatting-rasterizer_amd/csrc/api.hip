@@ -60,7 +60,9 @@ size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max
     for (int b = 0; b < 2; ++b) ws->pval[b] = static_cast<uint32_t *>(take(4 * np));
     ws->ranges = static_cast<uint2 *>(take(sizeof(uint2) * (size_t)ws->tiles_x * ws->tiles_y));
     ws->cranges = static_cast<uint2 *>(take(sizeof(uint2) * (size_t)ws->ctiles_x * ws->ctiles_y));
-    ws->pexp = static_cast<uint32_t *>(take(4 * 4 * np));
+    // the expanded per-tile lists exist only where coarse binning can run (frames up to 4096 px, ids and slots within its packing):
+    // 16 B per pair slot that every other workspace is spared
+    ws->pexp = coarse_capable(*ws) ? static_cast<uint32_t *>(take(4 * 4 * np)) : nullptr;
     const size_t order_slots = 8 * (size_t)((ws->tiles_y + 7) / 8) * ws->tiles_x;
     ws->tile_order = static_cast<int *>(take(sizeof(int) * order_slots));
     ws->blend_stats = static_cast<uint32_t *>(take(sizeof(uint32_t) * BLEND_STAT_WORDS * order_slots));
@@ -84,9 +86,10 @@ static int check_frame(int64_t n, const GsrCamera *cam, const GsrOptions *opts, 
     }
     if (opts->draw_limit < 0) { set_error("bad draw_limit %d", opts->draw_limit); return GSR_ERR_BAD_ARG; }
     if (opts->output_dtype != 0 && opts->output_dtype != 1) { set_error("bad output_dtype %d", opts->output_dtype); return GSR_ERR_BAD_ARG; }
-    if (opts->blend_impl < 0 || opts->blend_impl > 2) { set_error("bad blend_impl %d", opts->blend_impl); return GSR_ERR_BAD_ARG; }
+    if (opts->blend_impl < 0 || opts->blend_impl > 1) { set_error("bad blend_impl %d", opts->blend_impl); return GSR_ERR_BAD_ARG; }
     if (opts->output_layout < 0 || opts->output_layout > 2) { set_error("bad output_layout %d", opts->output_layout); return GSR_ERR_BAD_ARG; }
     if (opts->depth_sort_passes < 0 || opts->depth_sort_passes > 4) { set_error("bad depth_sort_passes %d", opts->depth_sort_passes); return GSR_ERR_BAD_ARG; }
+    if (opts->keep_flags != 0 && opts->keep_flags != 1) { set_error("bad keep_flags %d", opts->keep_flags); return GSR_ERR_BAD_ARG; }
     if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) { set_error("workspace must be 256-byte aligned"); return GSR_ERR_BAD_ARG; }
     const size_t need = carve_workspace(workspace, n, cam->width, cam->height, max_pairs, ws);
     if (workspace_bytes < need) {
@@ -230,9 +233,10 @@ static int preprocess_impl(const GsrScene *scene, const GsrCamera *cam, const Gs
     rc = check_frame(scene->n, cam, opts, 0, workspace, workspace_bytes, &ws);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static_assert(offsetof(FrameCtrl, depth_key_max) % 4 == 0 && offsetof(FrameCtrl, batch_overflow) % 4 == 0, "FrameCtrl is cleared by words");
-    // never cleared here: depth_key_max (the depth sort zeroes it itself once consumed)
-    const int reset_words = (int)((keep_batch_words ? offsetof(FrameCtrl, batch_overflow) : offsetof(FrameCtrl, depth_key_max)) / 4);
+    static_assert(sizeof(FrameCtrl) % 4 == 0 && offsetof(FrameCtrl, batch_overflow) % 4 == 0, "FrameCtrl is cleared by words");
+    // a fresh workspace may hold anything: the default clears the whole block (so does a 0xFF-filled one render correctly);
+    // keep_flags / the later views of a batch keep the sticky record at its tail
+    const int reset_words = (int)((keep_batch_words || opts->keep_flags ? offsetof(FrameCtrl, batch_overflow) : sizeof(FrameCtrl)) / 4);
     return launch_preprocess(*scene, *cam, *opts, ws, debug, reset_words, s);
 }
 
@@ -333,19 +337,25 @@ int gsr_render_batch_slots(const GsrScene *scene, const GsrCamera *cams, int32_t
 int gsr_read_stats(void *workspace, size_t workspace_bytes, GsrStats *out, void *stream)
 {
     if (!workspace || !out || workspace_bytes < sizeof(FrameCtrl)) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
-    static_assert(sizeof(GsrStats) == 40, "GsrStats is the head of FrameCtrl");
+    static_assert(sizeof(GsrStats) == 40 && offsetof(FrameCtrl, digit_tot) == sizeof(GsrStats), "GsrStats is the head of FrameCtrl");
     hipStream_t s = static_cast<hipStream_t>(stream);
     {  // total the blend's per-workgroup counters; the kernel finds them through the offsets kept in FrameCtrl
         const int rc = launch_blend_stats(static_cast<FrameCtrl *>(workspace), workspace_bytes, s);
         if (rc != GSR_OK) return rc;
     }
-    GSR_HIP(hipMemcpyAsync(out, workspace, sizeof(GsrStats), hipMemcpyDeviceToHost, s));
+    // the whole control block (2 KB): GsrStats is its head, the sticky record of earlier frames its tail
+    FrameCtrl host;
+    GSR_HIP(hipMemcpyAsync(&host, workspace, sizeof(FrameCtrl), hipMemcpyDeviceToHost, s));
     GSR_HIP(hipStreamSynchronize(s));
+    memcpy(out, &host, sizeof(GsrStats));
     if (out->overflow & 1u) {
         set_error("pair overflow: the frame needs %u (gaussian,tile) pairs", out->n_pairs_bbox);
         return GSR_ERR_PAIR_OVERFLOW;
     }
     if (out->overflow & 2u) {
+        // the flag is sticky over a batch / a run of keep_flags frames while sort_passes describes the LAST frame: report what
+        // the worst frame needed, or a caller that re-renders with "GsrStats.sort_passes" could be handed its own bound back
+        out->sort_passes = std::max(out->sort_passes, host.batch_sort_passes);
         set_error("the depth sort needs %u passes, more than depth_sort_passes allowed", out->sort_passes);
         return GSR_ERR_SORT_PASSES;
     }

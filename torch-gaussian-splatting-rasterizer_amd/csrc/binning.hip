@@ -394,7 +394,8 @@ static int ceil_log2(int v)
 TileKeying tile_keying(const Workspace &ws)
 {
     TileKeying k;
-    k.coarse = rect_fits_8bit(ws) && ws.max_pairs <= (int64_t)0x3FFFFFFF && ws.n <= ((int64_t)1 << COARSE_ID_BITS);
+    static_assert(COARSE_ID_BITS == 28, "coarse_capable() in gsr_internal.h states the same limits");
+    k.coarse = coarse_capable(ws);
     if (k.coarse) {
         const char *e = std::getenv("GSR_FINE_BINNING");
         if (e && e[0] == '1') k.coarse = false;

@@ -668,7 +668,6 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(256), 0, s, ws.ranges, ws.ctrl, a.tiles_x, a.row_begin, a.row_step, a.rows,
                        slots_per_group, ws.tile_order,
                        (uint32_t)(reinterpret_cast<const char *>(ws.blend_stats) - reinterpret_cast<const char *>(ws.ctrl)));
-    if (opts.blend_impl == 2) return launch_blend_mfma(a, 8u * (unsigned)slots_per_group, s);
     if (opts.blend_impl == 1) hipLaunchKernelGGL(blend_kernel, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     else if (a.rows * a.tiles_x >= BLEND_HALF_MIN_TILES) hipLaunchKernelGGL(blend_walk_kernel<2>, dim3(8u * (unsigned)slots_per_group), dim3(128), 0, s, a);
     else hipLaunchKernelGGL(blend_walk_kernel<1>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);

@@ -1,4 +1,4 @@
-// blend_args.h — kernel arguments shared by the two blend implementations.
+// blend_args.h — kernel arguments of the blend kernels.
 #pragma once
 #include "gsr_internal.h"
 
@@ -36,7 +36,5 @@ __device__ __forceinline__ void store_rgb(const BlendArgs &a, size_t o, float r,
         p[0] = r; p[1] = g; p[2] = b;
     }
 }
-
-int launch_blend_mfma(const BlendArgs &a, unsigned grid, hipStream_t s);
 
 }  // namespace gsr

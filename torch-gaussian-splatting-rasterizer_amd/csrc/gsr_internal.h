@@ -30,12 +30,13 @@ struct FrameCtrl {
     uint32_t sort_bits_rest; //   after the first.  Written by the pass-0 rowscan (with sort_passes).
     uint32_t n_cpairs;       // coarse binning: 32x32-cell pairs that survive the sort's drop (count of the coarse ranges pass)
     uint32_t n_records;      // multi-GPU shard: records entering the depth sort (= this rank's visible gaussians; preprocess.hip)
-    uint32_t _pad0;
-    // ---- everything below survives the per-frame clear ----
-    uint32_t batch_overflow; // sticky across the views of gsr_render_batch: bit 0 pair overflow, bit 1 depth sort short of passes
-    uint32_t batch_need;     // largest D seen in the batch
-    uint32_t depth_key_max;  // running maximum of the valid depth keys (pass-0 histogram); consumed and zeroed by the pass-0
-                             // rowscan.  Garbage in a fresh workspace only makes the first frame sort over more bits.
+    uint32_t depth_key_max;  // maximum of the frame's valid depth keys (pass-0 histogram).  Cleared with the frame AND by the pass-0
+                             // rowscan once consumed (gsr_bin_sort may be repeated on one gsr_preprocess).
+    // ---- everything below survives the per-frame clear of a frame rendered with GsrOptions.keep_flags (and of the later views
+    // ---- of a batch): the record of what went wrong in ANY frame since the last full clear
+    uint32_t batch_overflow;     // bit 0 pair overflow, bit 1 depth sort short of passes
+    uint32_t batch_need;         // largest D seen
+    uint32_t batch_sort_passes;  // most radix passes any frame's depth sort has needed
     uint32_t _pad1;
 };
 constexpr int BLEND_STAT_WORDS = 8;  // per launch slot: [0..3] evaluated entries of waves 0..3, [4] staged entries
@@ -123,6 +124,9 @@ struct TileKeying {
 };
 TileKeying tile_keying(const Workspace &ws);
 inline bool rect_fits_8bit(const Workspace &ws) { return ws.tiles_x <= 256 && ws.tiles_y <= 256; }
+// Can this workspace bin per 32x32 cell (binning.hip)?  Needs the packed rect, pair values of 28 id bits + 4 mask bits, and the
+// expanded lists (4 words per pair slot) indexable in 32 bits.  Decides the workspace LAYOUT (pexp), so it depends on nothing else.
+inline bool coarse_capable(const Workspace &ws) { return rect_fits_8bit(ws) && ws.max_pairs <= (int64_t)0x3FFFFFFF && ws.n <= ((int64_t)1 << 28); }
 // A multi-GPU shard's preprocess (preprocess.hip) hands the depth sort a compact list of (key, id, rect) records of the rank's
 // visible gaussians instead of one key per gaussian.  Progressive frames (draw_limit) rank ALL gaussians the reference
 // draws, so they take the whole-frame path.

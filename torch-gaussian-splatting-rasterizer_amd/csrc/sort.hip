@@ -110,10 +110,13 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t *__restrict
         const uint32_t rest = bits > DEPTH_DIGIT_BITS ? bits - DEPTH_DIGIT_BITS : 0u;
         const uint32_t rest_passes = (rest + DEPTH_DIGIT_BITS - 1) / DEPTH_DIGIT_BITS;
         ctrl->sort_passes = 1u + rest_passes;
+        // what gsr_read_stats reports when the bound was too small: the most any frame since the last full clear has needed (a batch's
+        // counters otherwise describe its LAST view, whose own plan may fit)
+        ctrl->batch_sort_passes = max(ctrl->batch_sort_passes, 1u + rest_passes);
         if (1u + rest_passes > (uint32_t)ps.enqueued) ctrl->batch_overflow |= 2u;  // the caller's bound was too small: the frame is wrong
         ctrl->sort_key_bits = bits;
         ctrl->sort_bits_rest = rest_passes ? (rest + rest_passes - 1) / rest_passes : 0u;
-        ctrl->depth_key_max = 0u;  // ready for the next frame's pass-0 histogram (stream-ordered behind this kernel)
+        ctrl->depth_key_max = 0u;  // consumed: a repeated gsr_bin_sort starts from 0 again (the frame clear zeroes it too)
     }
     const uint32_t n = load_count(n_dev, n_bound);
     const int nblk = (int)(((unsigned long long)n + TILE - 1) / TILE);

@@ -18,6 +18,7 @@ from ._lib import GsrCamera, GsrDebugOut, GsrOptions, GsrScene, GsrStats, check,
 from .utils import pack_gaussians
 
 TILE = 16
+MAX_RETRIES = 6  # re-renders of one frame / batch after an exceeded bound (pair buffer, depth-sort passes) before giving up
 
 
 def _require_cuda(t: torch.Tensor, name: str) -> None:
@@ -83,7 +84,7 @@ def make_camera(qvec, tvec, fx_full: float, fy_full: float, cam_width: int, cam_
 
 def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_row_begin: int = 0, tile_row_step: int = 1,
                  output_layout: int = 0, no_footprint_cull: bool = False, blend_impl: int = 0, draw_limit: int = 0,
-                 output_bf16: bool = False, depth_sort_passes: int = 0) -> GsrOptions:
+                 output_bf16: bool = False, depth_sort_passes: int = 0, keep_flags: bool = False) -> GsrOptions:
     o = _lib.default_options()
     o.reference_compat = 1 if reference_compat else 0
     o.early_out_T = float(early_out_T)
@@ -94,7 +95,8 @@ def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_r
     o.blend_impl = int(blend_impl)
     o.draw_limit = int(draw_limit)
     o.output_dtype = 1 if output_bf16 else 0  # frame stored as bfloat16; accumulation stays fp32
-    o.depth_sort_passes = int(depth_sort_passes)  # 0: no bound (a Rasterizer fills in what it has learned from its frames' counters)
+    o.depth_sort_passes = int(depth_sort_passes)  # 0: no bound (Rasterizer.render / render_batch fill in what the frames' counters have taught them)
+    o.keep_flags = 1 if keep_flags else 0         # Rasterizer.enqueue sets it itself for the frames after the first since the last stats()
     return o
 
 
@@ -113,7 +115,8 @@ class Rasterizer:
         # are read): passed as GsrOptions.depth_sort_passes so that the passes a frame does not need are not even enqueued
         self.sort_passes = 0
         self._ws: Optional[torch.Tensor] = None
-        self._rendered = True
+        self._rendered = False     # a frame has run on the workspace
+        self._chained = False      # frames have been enqueued since the last stats(): the next one keeps their overflow record
         self._ws_key = None
         self.last_stats: Optional[Dict[str, int]] = None
 
@@ -129,6 +132,7 @@ class Rasterizer:
             # running key maximum (the one word libgsr carries from frame to frame) starts at 0 instead of garbage
             self._ws[: min(4096, nbytes)].zero_()
             self._ws_key = key
+            self._rendered = self._chained = False
         return self._ws
 
     def _out_shape(self, cam: GsrCamera, opts: GsrOptions):
@@ -139,8 +143,11 @@ class Rasterizer:
         rows = shard_rows(cam.height, opts.tile_row_begin, opts.tile_row_step) * TILE
         return (rows, cam.width, 3), (rows, cam.width)
 
-    def _bounded(self, opts: GsrOptions) -> GsrOptions:
-        """opts with the learned depth-sort bound filled in (a copy), unless the caller set one."""
+    def bounded(self, opts: Optional[GsrOptions] = None) -> GsrOptions:
+        """opts with the learned depth-sort bound filled in (a copy), unless the caller set one.  render() / render_batch()
+        apply it themselves (they check every frame and re-render); for enqueue() / FramesInFlight.submit() the caller opts
+        in with this — the frames are then unchecked until the next stats(), which reports ANY of them that exceeded it."""
+        opts = opts or make_options()
         if opts.depth_sort_passes != 0 or self.sort_passes == 0:
             return opts
         o = GsrOptions.from_buffer_copy(opts)
@@ -150,9 +157,10 @@ class Rasterizer:
     # -- one frame ------------------------------------------------------------------------------
     def enqueue(self, cam: GsrCamera, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None,
                 final_T: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Enqueue one frame on the current stream; no host synchronisation, no check of the two caller-supplied bounds
-        (max_pairs, the depth-sort passes learned so far): stats() / render() report a frame that exceeded either."""
-        opts = self._bounded(opts or make_options())
+        """Enqueue one frame on the current stream with `opts` as given; no host synchronisation and no check of the
+        caller's bounds (max_pairs; opts.depth_sort_passes if set).  The frames enqueued since the last stats() are chained
+        with GsrOptions.keep_flags, so the next stats() / render() reports a bound exceeded by ANY of them, not only the last."""
+        opts = opts or make_options()
         ws = self._workspace(cam.width, cam.height)
         shape, _ = self._out_shape(cam, opts)
         dtype = torch.bfloat16 if opts.output_dtype == 1 else torch.float32
@@ -163,54 +171,72 @@ class Rasterizer:
         elif tuple(out.shape) != shape or out.dtype != dtype or not out.is_contiguous() or not out.is_cuda:
             raise ValueError(f"out must be a contiguous {dtype} CUDA tensor of shape {shape}")
         if out.numel() == 0:  # a shard that owns no tile row (more ranks than tile rows): nothing to render
-            self._rendered = False
             return out
-        self._rendered = True
+        if self._chained and not opts.keep_flags:
+            opts = GsrOptions.from_buffer_copy(opts)
+            opts.keep_flags = 1
         sc = self.scene.c_struct()
         tptr = final_T.data_ptr() if final_T is not None else None
         check(lib.gsr_render_forward(C.byref(sc), C.byref(cam), C.byref(opts), self.max_pairs, ws.data_ptr(), ws.numel(),
                                      out.data_ptr(), tptr, _stream_ptr(self.scene.device)))
+        self._rendered = self._chained = True
         return out
 
     def stats(self) -> Dict[str, int]:
-        """Counters of the last enqueued frame (synchronises the stream).  Raises GsrPairOverflow on overflow."""
-        if not self._rendered:  # the last enqueue was an empty shard: no kernel ran, nothing to read
+        """Counters of the last enqueued frame (synchronises the stream); its overflow record covers every frame since the
+        previous stats().  Raises GsrPairOverflow / GsrSortPasses when one of them exceeded a bound."""
+        if not self._rendered:  # nothing has run on this workspace (only empty shards so far): nothing to read
             self.last_stats = {k: 0 for k, _ in GsrStats._fields_ if not k.startswith("_")}
             return self.last_stats
         st = GsrStats()
         rc = lib.gsr_read_stats(self._ws.data_ptr(), self._ws.numel(), C.byref(st), _stream_ptr(self.scene.device))
+        self._chained = False  # the next frame starts from a cleared control block
         self.last_stats = st.as_dict()
-        self.sort_passes = max(self.sort_passes, int(st.sort_passes))  # also when the frame was short of passes: the retry has them
+        self.sort_passes = max(self.sort_passes, int(st.sort_passes))  # also when a frame was short of passes: the retry has them
         check(rc)
         return self.last_stats
 
+    def _grow_pairs(self, slack_div: int) -> None:
+        """After GsrPairOverflow: room for what the worst frame needed, or give up when that cannot be had."""
+        need = int(self.last_stats["n_pairs_bbox"])
+        if need >= _lib.GSR_MAX_PAIRS:
+            raise _lib.GsrError(_lib.GSR_ERR_PAIR_OVERFLOW, f"the frame needs {need} pairs, more than libgsr can index")
+        grown = int(min(_lib.GSR_MAX_PAIRS, need + need // slack_div + 1024))
+        if grown <= self.max_pairs:
+            raise _lib.GsrError(_lib.GSR_ERR_PAIR_OVERFLOW, f"pair overflow persists at max_pairs = {self.max_pairs} (need {need})")
+        self.max_pairs = grown
+
     def render(self, cam: GsrCamera, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None,
                return_T: bool = False):
-        """Render one frame and verify it is complete; grows the pair buffer and retries on overflow."""
+        """Render one frame and verify it is complete: grows the pair buffer / raises the learned depth-sort bound and
+        re-renders when the frame exceeded one (at most MAX_RETRIES times)."""
         opts = opts or make_options()
-        while True:
+        unbounded, tried = False, -1
+        for _ in range(MAX_RETRIES + 1):
             final_T = None
             if return_T:
                 _, tshape = self._out_shape(cam, opts)
                 final_T = torch.ones(tshape, dtype=torch.float32, device=self.scene.device)
-            img = self.enqueue(cam, opts, out, final_T)
+            # (frames enqueued before this one and not yet checked share its overflow record: if one of THEM exceeded a bound,
+            # this frame is re-rendered once with room for it — nothing is hidden and nothing is wrong)
+            img = self.enqueue(cam, opts if unbounded else self.bounded(opts), out, final_T)
             try:
                 self.stats()
             except _lib.GsrPairOverflow:
-                need = int(self.last_stats["n_pairs_bbox"])
-                if need >= _lib.GSR_MAX_PAIRS:
-                    raise
-                self.max_pairs = int(min(_lib.GSR_MAX_PAIRS, need + need // 8 + 1024))
+                self._grow_pairs(8)
                 continue
             except _lib.GsrSortPasses:
                 if opts.depth_sort_passes != 0:
                     raise  # the caller's own bound
-                continue   # stats() has raised the learned bound
+                unbounded = self.sort_passes <= tried  # stats() raises the learned bound; if it did not grow, enqueue every pass
+                tried = self.sort_passes
+                continue
             return (img, final_T) if return_T else img
+        raise _lib.GsrError(_lib.GSR_ERR_BAD_ARG, f"frame still incomplete after {MAX_RETRIES} re-renders: {self.last_stats}")
 
     def render_batch(self, cams, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Several views of the resident scene in one call: [B,H,W,3].  Pair buffers are sized on the fly: a view
-        that overflows makes the batch re-run with room for it."""
+        """Several views of the resident scene in one call: [B,H,W,3].  Pair buffers and the depth-sort bound are sized on
+        the fly: a view that exceeds one makes the batch re-run with room for the worst view (at most MAX_RETRIES times)."""
         opts = opts or make_options()
         if opts.output_layout != 0 or opts.tile_row_step > 1:
             raise ValueError("render_batch renders whole [H,W,3] frames")
@@ -222,22 +248,27 @@ class Rasterizer:
             out = torch.empty((len(cams), H, W, 3), dtype=dtype, device=self.scene.device)
         elif tuple(out.shape) != (len(cams), H, W, 3) or out.dtype != dtype or not out.is_contiguous() or not out.is_cuda:
             raise ValueError(f"out must be a contiguous {dtype} CUDA tensor of shape {(len(cams), H, W, 3)}")
+        if not cams:
+            return out
         sc = self.scene.c_struct()
-        while True:
+        unbounded = False
+        for _ in range(MAX_RETRIES + 1):
             ws = self._workspace(W, H)
-            # overflow is only visible per view: check every view's counters cheaply by rendering view by view
-            # when the batch is small, else trust fit_pairs() and check the last one
-            check(lib.gsr_render_batch(C.byref(sc), arr, len(cams), C.byref(self._bounded(opts)), self.max_pairs, ws.data_ptr(), ws.numel(),
+            o = GsrOptions.from_buffer_copy(opts if unbounded else self.bounded(opts))
+            o.keep_flags = 0  # view 0 clears the record, libgsr chains the rest: the counters then speak for every view
+            check(lib.gsr_render_batch(C.byref(sc), arr, len(cams), C.byref(o), self.max_pairs, ws.data_ptr(), ws.numel(),
                                        out.data_ptr(), H * W * 3, _stream_ptr(self.scene.device)))
+            self._rendered = self._chained = True
             try:
                 self.stats()
                 return out
             except _lib.GsrPairOverflow:
-                need = int(self.last_stats["n_pairs_bbox"])
-                self.max_pairs = int(min(_lib.GSR_MAX_PAIRS, need + need // 4 + 1024))
+                self._grow_pairs(4)
             except _lib.GsrSortPasses:
                 if opts.depth_sort_passes != 0:
                     raise
+                unbounded = o.depth_sort_passes >= self.sort_passes  # the reported need did not exceed what was enqueued: play safe
+        raise _lib.GsrError(_lib.GSR_ERR_BAD_ARG, f"batch still incomplete after {MAX_RETRIES} re-renders: {self.last_stats}")
 
     def fit_pairs(self, cam: GsrCamera, opts: Optional[GsrOptions] = None, slack: float = 1.25) -> int:
         """Size the pair buffers to this view: one probing frame, then max_pairs = slack * D (+ margin).
@@ -306,7 +337,8 @@ class FramesInFlight:
 
     def submit(self, cam: GsrCamera, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None,
                slot: Optional[int] = None) -> int:
-        """Enqueue one frame on the next slot's stream (round robin) and return the slot."""
+        """Enqueue one frame on the next slot's stream (round robin) and return the slot.  Unchecked, with `opts` as given
+        (Rasterizer.enqueue): stats(slot) afterwards speaks for every frame the slot has rendered since its last stats()."""
         k = self._next if slot is None else int(slot)
         if slot is None:
             self._next = (self._next + 1) % len(self.rasterizers)
@@ -330,22 +362,29 @@ class FramesInFlight:
             out = torch.empty((len(cams), H, W, 3), dtype=dtype, device=dev)
         elif tuple(out.shape) != (len(cams), H, W, 3) or out.dtype != dtype or not out.is_contiguous() or not out.is_cuda:
             raise ValueError(f"out must be a contiguous {dtype} CUDA tensor of shape {(len(cams), H, W, 3)}")
+        if not cams:
+            return out
         sc = self.scene.c_struct()
         n = len(self.rasterizers)
         cur = torch.cuda.current_stream(dev)
-        while True:
+        r0 = self.rasterizers[0]
+        unbounded = False
+        for _ in range(MAX_RETRIES + 1):
             wss = [r._workspace(W, H) for r in self.rasterizers]  # all of one size: the slots share max_pairs
             for st in self.streams:
                 st.wait_stream(cur)  # `out` (and the workspaces) may have been allocated / used on the current stream
             ws_arr = (C.c_void_p * n)(*[w.data_ptr() for w in wss])
             st_arr = (C.c_void_p * n)(*[int(st.cuda_stream) for st in self.streams])
             self.set_sort_passes(max(r.sort_passes for r in self.rasterizers))
-            check(lib.gsr_render_batch_slots(C.byref(sc), arr, len(cams), C.byref(self.rasterizers[0]._bounded(opts)),
-                                             self.rasterizers[0].max_pairs, ws_arr, wss[0].numel(), st_arr, n, out.data_ptr(), H * W * 3))
-            for r in self.rasterizers:
-                r._rendered = True
+            o = GsrOptions.from_buffer_copy(opts if unbounded else r0.bounded(opts))
+            o.keep_flags = 0  # a slot's first view clears its record, libgsr chains the slot's later views
+            check(lib.gsr_render_batch_slots(C.byref(sc), arr, len(cams), C.byref(o), r0.max_pairs, ws_arr, wss[0].numel(), st_arr, n,
+                                             out.data_ptr(), H * W * 3))
+            used = min(n, len(cams))
+            for r in self.rasterizers[:used]:
+                r._rendered = r._chained = True
             need, short = 0, False
-            for k in range(min(n, len(cams))):
+            for k in range(used):
                 try:
                     self.stats(k)
                 except _lib.GsrPairOverflow:
@@ -359,7 +398,12 @@ class FramesInFlight:
             if need == 0 and not short:
                 return out
             if need:
+                if need >= _lib.GSR_MAX_PAIRS:
+                    raise _lib.GsrError(_lib.GSR_ERR_PAIR_OVERFLOW, f"a view needs {need} pairs, more than libgsr can index")
                 self.set_max_pairs(int(min(_lib.GSR_MAX_PAIRS, need + need // 4 + 1024)))
+            if short:
+                unbounded = o.depth_sort_passes >= max(r.sort_passes for r in self.rasterizers)  # the need did not grow: play safe
+        raise _lib.GsrError(_lib.GSR_ERR_BAD_ARG, f"batch still incomplete after {MAX_RETRIES} re-renders")
 
     def wait(self, slot: int) -> None:
         torch.cuda.current_stream(self.scene.device).wait_stream(self.streams[slot])
