@@ -50,6 +50,7 @@ METRIC = {
     "box4k": "frames/sec @4K, synthetic 20M gaussians (configs[4])",
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_NS, EXP_NS = 1.1, 3.4  # measured issue cost per wave64 instruction per SIMD, 8 waves per SIMD (tools/valu_microbench.hip)
 
 
 def host_threads() -> int:
@@ -79,7 +80,7 @@ def parse():
                     help="single: every step renders --camera; all: steps cycle over the whole camera set (configs[3])")
     ap.add_argument("--input_dir", default="", help="real data: MipNeRF-360 scene dir with sparse/0/{images,cameras}.bin")
     ap.add_argument("--trained_model_path", default="", help="real data: INRIA model dir (point_cloud/iteration_30000/point_cloud.ply)")
-    ap.add_argument("--legs", default="configs2,early_out,garden", help="extra legs at N=1 (comma list; '' = none)")
+    ap.add_argument("--legs", default="configs2,early_out,garden,box4k", help="extra legs at N=1 (comma list; '' = none)")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="independent frames in flight per GPU, each on its own HIP stream and workspace (1 = one stream; the "
                          "single-stream figure is reported beside the headline either way)")
@@ -162,6 +163,73 @@ def pmc_profile(workload):
         return json.load(open(tfile)).get(workload, {})
     except Exception:
         return {}
+
+
+def stage_profile(R, scene, cam, opts, out_shape, tiles, reps, sh_half, prof, dev):
+    """Per-stage times of one frame (HIP events around gsr_preprocess / gsr_bin_sort / gsr_blend on ONE stream, mean over `reps`
+    frames after 3 untimed ones) and the roofline object of the dominant kernel, the blend.
+
+    roofline.achieved / peak / frac are the CONTRACT figure: algorithmic bytes 40 E + 12 P + 8 tiles per launch
+    over the kernel's time against 8 TB/s.  The kernel is not bound by HBM but by vector-ALU issue (exact per-pixel evaluation:
+    ~13 issue slots per evaluated (8x8 quadrant, entry), a quarter-rate v_exp_f32 among them), so `bound` says "valu" and the
+    fractions that describe it ride along: valu_issue_frac (VALU wave-instructions per launch, from the committed rocprofv3
+    counters, at one issue per 2 cycles per SIMD at the profiled clock) and valu_frac_calibrated (the same instructions priced
+    with tools/valu_microbench.hip's measured rates on this chip: 1.1 ns per plain VALU wave-instruction per SIMD, 3.4 ns per
+    v_exp_f32 — what a kernel made of nothing else would need)."""
+    import ctypes as C
+
+    from gsr_amd._lib import check, lib
+
+    n = scene.n
+    W, H = cam.width, cam.height
+    ws = R._workspace(W, H)
+    sc = scene.c_struct()
+    out = torch.empty(out_shape, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    sp = int(stream.cuda_stream)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
+    for i in range(reps + 3):
+        e = ev[max(i - 3, 0)]
+        e[0].record(stream)
+        check(lib.gsr_preprocess(C.byref(sc), C.byref(cam), C.byref(opts), ws.data_ptr(), ws.numel(), None, sp))
+        e[1].record(stream)
+        check(lib.gsr_bin_sort(n, C.byref(cam), C.byref(opts), R.max_pairs, ws.data_ptr(), ws.numel(), sp))
+        e[2].record(stream)
+        check(lib.gsr_blend(n, C.byref(cam), C.byref(opts), R.max_pairs, ws.data_ptr(), ws.numel(), out.data_ptr(), None, sp))
+        e[3].record(stream)
+    torch.cuda.synchronize(dev)
+    st = R.stats()
+    stage = [float(np.mean([e[k].elapsed_time(e[k + 1]) for e in ev])) for k in range(3)]
+    E, P, V = st["fetched_entries"], out.shape[0] * out.shape[1], st["n_visible"]  # E = entries actually fetched (SURVEY.md §8(d))
+    blend_bytes = 40.0 * E + 12.0 * P + 8.0 * tiles
+    pre_bytes = (140.0 if sh_half else 236.0) * n + 64.0 * V
+    achieved = blend_bytes / (stage[2] * 1e-3) / 1e9
+    roof = {
+        "kernel": "gsr::blend_walk_kernel", "bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": prof.get("blend_kernel_bytes_per_launch"),
+        "algorithmic_bytes_per_launch": blend_bytes, "avg_kernel_ms": stage[2],
+        "limiter": "vector-ALU issue (exact per-pixel evaluation: ~70 flop and 6.4 exp per algorithmic byte, SURVEY.md §7 hard part 1): "
+                   "achieved / peak / frac are the HBM contract figure, valu_* the fractions of the pipe that bounds the kernel",
+        "note": "avg_kernel_ms: HIP events around the stage on ONE stream, one frame in flight (profiles/*kernel_stats.csv, collected "
+                "with --frames-in-flight 1, agrees); in the timed loop kernels of the frames in flight share the machine and "
+                "their individual durations stretch.  traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction, an upper bound for "
+                "gathered 48-B records) + WRITE_SIZE, separate --pmc passes, from profiles/",
+    }
+    # honesty figures (SURVEY.md §8(d)): pixel evaluations, and the pipes that bound the kernel, priced from the committed counters
+    roof["pixel_evaluations"] = 64.0 * st["wave_entries"]
+    if prof.get("valu_insts_per_wave_entry"):
+        clk = prof.get("clock_ghz", 2.0)
+        valu = st["wave_entries"] * prof["valu_insts_per_wave_entry"]  # wave-instructions per launch (scales with the evaluated entries)
+        t = stage[2] * 1e-3
+        roof["valu_issue_frac"] = valu * 2.0 / t / (1024 * clk * 1e9)
+        # calibrated: every VALU wave-instruction at the microbenchmark's 1.1 ns per SIMD, + 2.3 ns more for each evaluation's v_exp_f32
+        roof["valu_frac_calibrated"] = (valu * VALU_NS + st["wave_entries"] * (EXP_NS - VALU_NS)) * 1e-9 / 1024 / t
+        roof["valu_calibration"] = {"plain_valu_ns_per_wave_instr_per_simd": VALU_NS, "v_exp_f32_ns": EXP_NS,
+                                    "source": "tools/valu_microbench.hip on MI355X, 8 waves per SIMD (profiles/r3_valu_microbench.txt)"}
+    if prof.get("lds_busy_frac") is not None:
+        roof["lds_busy_frac_profiled"] = prof["lds_busy_frac"]
+    return {"roofline": roof, "stage_ms": {"preprocess": stage[0], "bin_sort": stage[1], "blend": stage[2]},
+            "stage_hbm_gbs": {"preprocess": pre_bytes / (stage[0] * 1e-3) / 1e9}, "stats": st}
 
 
 def main():
@@ -329,68 +397,14 @@ def main():
     # ---- rank 0: per-stage timing + roofline of ITS shard (the whole frame at N=1), outside the timed region; at N=1 also
     # ---- PSNR vs the oracle, the extra legs and the CPU baseline -------------------------------------------------------
     if rank == 0:
-        import ctypes as C
-
         if world == 1:
             frame = R.enqueue(cam, opts, out=strip_view)  # the frame checked against the oracle below is camera 0's
-
-        from gsr_amd._lib import check, lib
-
-        ws = R._workspace(W, H)
-        sc = scene.c_struct()
         full_opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl, depth_sort_passes=R.sort_passes,
                                           **(plan.shard_options(rank) if world > 1 else {}))
-        out = torch.empty(plan.strip_shape(rank) if world > 1 else (H, W, 3), dtype=torch.float32, device=dev)
-        stream = torch.cuda.current_stream(dev)
-        sp = int(stream.cuda_stream)
-        reps = max(10, min(50, args.steps))
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
-        for i in range(reps + 3):
-            e = ev[max(i - 3, 0)]
-            e[0].record(stream)
-            check(lib.gsr_preprocess(C.byref(sc), C.byref(cam), C.byref(full_opts), ws.data_ptr(), ws.numel(), None, sp))
-            e[1].record(stream)
-            check(lib.gsr_bin_sort(n, C.byref(cam), C.byref(full_opts), R.max_pairs, ws.data_ptr(), ws.numel(), sp))
-            e[2].record(stream)
-            check(lib.gsr_blend(n, C.byref(cam), C.byref(full_opts), R.max_pairs, ws.data_ptr(), ws.numel(), out.data_ptr(),
-                                None, sp))
-            e[3].record(stream)
-        torch.cuda.synchronize(dev)
-        st = R.stats()
-        stage = [float(np.mean([e[k].elapsed_time(e[k + 1]) for e in ev])) for k in range(3)]
-        tiles = ((W + 15) // 16) * ((H + 15) // 16)
-        E, P, V = st["fetched_entries"], out.shape[0] * out.shape[1], st["n_visible"]  # E = entries actually fetched
-        if world > 1:
-            tiles = len(plan.rows[rank]) * ((W + 15) // 16)
-        blend_bytes = 40.0 * E + 12.0 * P + 8.0 * tiles
-        pre_bytes = (140.0 if args.sh_half else 236.0) * n + 64.0 * V
-        achieved = blend_bytes / (stage[2] * 1e-3) / 1e9
-        prof = pmc_profile(args.workload) if world == 1 else {}
-        result["roofline"] = {
-            "kernel": "gsr::blend_walk_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": prof.get("blend_kernel_bytes_per_launch"),
-            "algorithmic_bytes_per_launch": blend_bytes, "avg_kernel_ms": stage[2],
-            "limiter": "on-chip: VALU issue + LDS reads (exact per-pixel evaluation: ~70 flop and 6.4 exp per algorithmic byte, "
-                       "SURVEY.md §7 hard part 1); HBM is not the bound, frac is the contract figure",
-            "note": "avg_kernel_ms: HIP events around the stage on ONE stream, one frame in flight (profiles/r2_kernel_stats.csv, collected "
-                    "with --frames-in-flight 1, agrees); in the timed loop kernels of the frames in flight share the machine and "
-                    "their individual durations stretch (profiles/r2_kernel_stats_frames_in_flight.csv: the same kernel averages "
-                    "0.60 ms there).  traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction, an upper bound for gathered 48-B "
-                    "records) + WRITE_SIZE, separate --pmc passes, from profiles/",
-        }
-        # honesty figures: pixel evaluations, and the two pipes that bound the kernel, priced from the committed
-        # counters: VALU wave-instructions per launch at one fp32 issue per 2 cycles per SIMD (1024 SIMDs), LDS-array cycles per
-        # launch (SQ_LDS_IDX_ACTIVE) over the kernel's cycles (GRBM_GUI_ACTIVE / 8 XCDs).  Both scale with evaluated entries.
-        evals = 64.0 * st["wave_entries"]
-        result["roofline"]["pixel_evaluations"] = evals
-        if prof.get("valu_insts_per_wave_entry"):
-            clk = prof.get("clock_ghz", 2.0)
-            result["roofline"]["valu_issue_frac"] = st["wave_entries"] * prof["valu_insts_per_wave_entry"] * 2.0 / (stage[2] * 1e-3) / (1024 * clk * 1e9)
-        if prof.get("lds_busy_frac") is not None:
-            result["roofline"]["lds_busy_frac_profiled"] = prof["lds_busy_frac"]
-        result["stage_ms"] = {"preprocess": stage[0], "bin_sort": stage[1], "blend": stage[2]}
-        result["stage_hbm_gbs"] = {"preprocess": pre_bytes / (stage[0] * 1e-3) / 1e9}
-        result["stats"] = st
+        prof = stage_profile(R, scene, cam, full_opts, plan.strip_shape(rank) if world > 1 else (H, W, 3),
+                             len(plan.rows[rank]) * ((W + 15) // 16) if world > 1 else ((W + 15) // 16) * ((H + 15) // 16),
+                             max(10, min(50, args.steps)), args.sh_half, pmc_profile(args.workload) if world == 1 else {}, dev)
+        result.update(prof)
         if world > 1:
             result["roofline"]["note"] = "rank 0's shard (interleaved tile rows); " + result["roofline"]["note"]
 
@@ -485,6 +499,28 @@ def main():
             result["garden"] = {"frames_per_s": steps_leg / el, "ms_per_step": 1e3 * el / steps_leg, "gaussians": gn,
                                 "stats": s, "note": "not the headline: BASELINE configs[1] stand-in (" + gdesc + "), fp32, exact; "
                                 "its oracle parity is tests/test_gpu_configs.py"}
+
+        # (4) BASELINE configs[4] on this GPU: 20 M uniform gaussians at 3840x2160, fp32, exact — its own stage times and its own
+        # roofline object (the config asks for "rocprof GB/s vs roofline": profiles/r3_box4k_* hold the rocprofv3 side of it)
+        if "box4k" in legs and args.workload != "box4k" and not args.gaussians:
+            R = scene = packed = fif = frames = leg_out = strip_view = frame = Rg = gscene = None  # the other scenes leave HBM
+            torch.cuda.empty_cache()
+            bcols, bcam_list, bn, bW, bH, bdesc = build_workload("box4k", args)
+            bscene = renderer.GaussianScene.from_columns(bcols, device=dev)
+            del bcols
+            bcam = renderer.make_camera(*bcam_list[0])
+            Rb = renderer.Rasterizer(bscene)
+            b_opts = renderer.make_options()
+            Rb.fit_pairs(bcam, b_opts)
+            b_out = torch.empty((bH, bW, 3), dtype=torch.float32, device=dev)
+            steps_b = max(5, min(args.steps, 30))
+            el = timed_frames(Rb, [bcam], b_opts, b_out, steps_b, 3, dev, min(S, 2))
+            bprof = stage_profile(Rb, bscene, bcam, Rb.bounded(b_opts), (bH, bW, 3), ((bW + 15) // 16) * ((bH + 15) // 16),
+                                  10, False, pmc_profile("box4k"), dev)
+            result["box4k"] = {"frames_per_s": steps_b / el, "ms_per_step": 1e3 * el / steps_b, "gaussians": bn, "width": bW, "height": bH,
+                               "frames_in_flight": min(S, 2), **bprof,
+                               "note": "not the headline: BASELINE configs[4] (" + bdesc + ") on ONE GPU, fp32, exact; its oracle parity "
+                                       "(125.6 dB at full size) is tests/test_gpu_configs.py"}
 
     if rank == 0:
         print(json.dumps(result), flush=True)

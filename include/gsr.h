@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 400 /* 0.4.0: GsrOptions.keep_flags; GsrStats.sort_passes reports the worst frame when the bound was exceeded; blend_impl 2
+#define GSR_VERSION 400 /* 0.4.0: GsrOptions.keep_flags, GsrOptions.accum_dtype; GsrStats.sort_passes reports the worst frame when the bound was exceeded; blend_impl 2
                             (matrix-pipe experiment) removed; the frame clear covers every word of the control block.  0.3.0: GsrOptions.depth_sort_passes, GsrStats.sort_passes, GSR_ERR_SORT_PASSES.  0.2.1: + gsr_render_batch_slots.
                             0.2.0: gsr_preprocess_geometry/_color removed (measured slower), gsr_read_stats takes a non-const workspace */
 
@@ -107,6 +107,11 @@ typedef struct GsrOptions {
                                  what the frames need — GsrStats.sort_passes of an earlier frame of the scene (3 whenever the depths stay
                                  within 0.2 .. 13 000): only that many are enqueued.  Verified on the device like max_pairs: a frame
                                  that needs more is flagged and gsr_read_stats returns GSR_ERR_SORT_PASSES. */
+    int32_t accum_dtype;      /* 0 (default): T and the colour sums are accumulated in fp32 registers.  1: they are rounded to bfloat16 after
+                                 every gaussian — BASELINE configs[2] as literally worded ("bf16 blend accumulator").  A measurement
+                                 option, not a fast path (it runs the plain-C blend kernel, whatever blend_impl says): 8 mantissa bits
+                                 cannot carry a transmittance through hundreds of layers, the frame lands far below the fp32 one
+                                 (tests/test_gpu_configs.py prints the PSNR; SURVEY.md §7.3 probed 41 dB on the CPU). */
     int32_t keep_flags;       /* 0 (default): the frame starts from a cleared control block (a fresh workspace needs no initialisation).
                                  1: the frame keeps the overflow record of the frames rendered before it on this workspace (bits of
                                  GsrStats.overflow, the largest D, the most depth-sort passes), so ONE gsr_read_stats after a run of
@@ -122,7 +127,7 @@ typedef struct GsrStats {
     uint32_t n_pairs;       /* E: entries of the per-tile lists the blend consumes (this shard; after footprint culling) */
     uint32_t overflow;      /* bit 0: D exceeded max_pairs (frame incomplete); bit 1: the depth sort needed more passes than
                                depth_sort_passes allowed (frame wrong) */
-    uint32_t max_list_len;  /* longest per-tile list */
+    uint32_t max_list_len;  /* longest list a blend workgroup walks: per 32x32 cell (frames wider than 4096 px: per 16x16 tile) */
     uint32_t sort_passes;   /* radix passes the depth sort of this frame needs (1..4): the bound to pass as depth_sort_passes.  When
                                overflow bit 1 is set: the most any frame since the last cleared one (keep_flags, batches) needed */
     uint64_t wave_entries;  /* (8x8 quadrant, entry) pairs the blend actually evaluated: 64 pixel evaluations each */

@@ -31,7 +31,7 @@ def test_struct_sizes_match_header():
 
     assert C.sizeof(_lib.GsrScene) == 56
     assert C.sizeof(_lib.GsrCamera) == 4 * (16 + 16 + 3 + 6) + 8
-    assert C.sizeof(_lib.GsrOptions) == 44 and _lib.GsrOptions.keep_flags.offset == 40
+    assert C.sizeof(_lib.GsrOptions) == 48 and _lib.GsrOptions.keep_flags.offset == 44 and _lib.GsrOptions.accum_dtype.offset == 40
     assert C.sizeof(_lib.GsrStats) == 40 and _lib.GsrStats.wave_entries.offset == 24 and _lib.GsrStats.fetched_entries.offset == 32
     assert C.sizeof(_lib.GsrDebugOut) == 72
 

@@ -750,9 +750,9 @@ def test_hand_scheduled_blend_walk_equals_the_plain_kernel(G):
 
 @pytest.mark.parametrize("name,prefix", [("medium", ""), ("f3_edge.npz", "a_"), ("f3_edge.npz", "b_")])
 def test_coarse_binning_builds_the_same_frame_as_fine_binning(G, monkeypatch, name, prefix):
-    """binning.hip: pairs are generated and sorted per 32x32 cell and then expanded into the four 16x16 tile lists; with
-    GSR_FINE_BINNING=1 they are generated per tile directly (the path frames wider than 4096 px always take).  Every tile list
-    holds the same gaussians in the same order up to entries whose footprint misses the tile (coarser emit-time culling keeps
+    """binning.hip: pairs are generated and sorted per 32x32 cell, and the blend of a tile keeps the cell-list entries that carry
+    its bit (blend.hip, TileList); with GSR_FINE_BINNING=1 pairs are generated per tile directly (the path frames wider than
+    4096 px always take).  Every tile walks the same gaussians in the same order up to entries whose footprint misses the tile (coarser emit-time culling keeps
     a few more; the blend's quadrant test rejects them): frames, T and the evaluated count must be identical — whole frame,
     shards (odd and even steps), progressive prefixes, culling off, a frame-covering gaussian (f3a), a frame that is not a
     multiple of 16 or 32 (f3b)."""

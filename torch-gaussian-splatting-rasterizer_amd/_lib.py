@@ -80,6 +80,7 @@ class GsrOptions(C.Structure):
         ("draw_limit", C.c_int32),
         ("output_dtype", C.c_int32),
         ("depth_sort_passes", C.c_int32),
+        ("accum_dtype", C.c_int32),
         ("keep_flags", C.c_int32),
     ]
 

@@ -60,9 +60,6 @@ size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max
     for (int b = 0; b < 2; ++b) ws->pval[b] = static_cast<uint32_t *>(take(4 * np));
     ws->ranges = static_cast<uint2 *>(take(sizeof(uint2) * (size_t)ws->tiles_x * ws->tiles_y));
     ws->cranges = static_cast<uint2 *>(take(sizeof(uint2) * (size_t)ws->ctiles_x * ws->ctiles_y));
-    // the expanded per-tile lists exist only where coarse binning can run (frames up to 4096 px, ids and slots within its packing):
-    // 16 B per pair slot that every other workspace is spared
-    ws->pexp = coarse_capable(*ws) ? static_cast<uint32_t *>(take(4 * 4 * np)) : nullptr;
     const size_t order_slots = 8 * (size_t)((ws->tiles_y + 7) / 8) * ws->tiles_x;
     ws->tile_order = static_cast<int *>(take(sizeof(int) * order_slots));
     ws->blend_stats = static_cast<uint32_t *>(take(sizeof(uint32_t) * BLEND_STAT_WORDS * order_slots));
@@ -89,6 +86,7 @@ static int check_frame(int64_t n, const GsrCamera *cam, const GsrOptions *opts, 
     if (opts->blend_impl < 0 || opts->blend_impl > 1) { set_error("bad blend_impl %d", opts->blend_impl); return GSR_ERR_BAD_ARG; }
     if (opts->output_layout < 0 || opts->output_layout > 2) { set_error("bad output_layout %d", opts->output_layout); return GSR_ERR_BAD_ARG; }
     if (opts->depth_sort_passes < 0 || opts->depth_sort_passes > 4) { set_error("bad depth_sort_passes %d", opts->depth_sort_passes); return GSR_ERR_BAD_ARG; }
+    if (opts->accum_dtype != 0 && opts->accum_dtype != 1) { set_error("bad accum_dtype %d", opts->accum_dtype); return GSR_ERR_BAD_ARG; }
     if (opts->keep_flags != 0 && opts->keep_flags != 1) { set_error("bad keep_flags %d", opts->keep_flags); return GSR_ERR_BAD_ARG; }
     if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) { set_error("workspace must be 256-byte aligned"); return GSR_ERR_BAD_ARG; }
     const size_t need = carve_workspace(workspace, n, cam->width, cam->height, max_pairs, ws);

@@ -19,7 +19,10 @@
 //           footprint (footprint.h): unreachable tiles (corners of oblique ellipses) are marked culled.
 //           Smaller rects skip the test (it needs a 32-B gather per gaussian; the blend culls per 8x8 quadrant anyway).
 //   sort    (sort.hip) stable radix sort by tile key, 2 passes for frames up to 4096 px
-//   ranges  boundaries of equal keys in the tile-sorted pair array -> ranges[tile] = [begin, end)
+//   ranges  boundaries of equal keys in the sorted pair array -> ranges[tile] (fine) / cranges[cell] (coarse) = [begin, end)
+// Coarse binning (frames up to 4096 px): pairs are generated and sorted per 32x32 CELL (2x2 tiles: half as many pairs), each
+// carrying in the top four bits of its value which of the cell's tiles the gaussian's tile rect covers (and this rank owns); the
+// blend of a tile walks its cell's list and keeps the entries with its bit (blend.hip, TileList).
 // Measured and rejected (round 2): generating the pairs INSIDE the first tile-sort pass (a histogram of rows-per-column
 // per block of 768 gaussians, then generate + rank + reorder 4096 pairs per round): it removes the emit kernel, a
 // histogram kernel and one write + two reads of the pair arrays, but a workgroup then walks its rounds serially with
@@ -101,14 +104,14 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t
                                                                   const FrameCtrl *ctrl, const ushort4 *__restrict__ rect, Shard sh,
                                                                   uint32_t *__restrict__ blk_sum, uint2 *__restrict__ ranges,
                                                                   int n_tiles, uint32_t draw_limit, uint2 *__restrict__ cranges, int n_ctiles,
-                                                                  FrameCtrl *ctrl_w)
+                                                                  FrameCtrl *ctrl_w, uint32_t ent_off)
 {
     __shared__ uint32_t scratch[8];
     const uint32_t n = ctrl->n_visible;
     if (COARSE) {  // the cell ranges are rebuilt every frame too, and the expansion totals E with atomics
         const uint32_t t = blockIdx.x * EMIT_THREADS + threadIdx.x;
         if (t < (uint32_t)n_ctiles) cranges[t] = make_uint2(0u, 0u);
-        if (t == 0) ctrl_w->n_pairs = 0u;
+        if (t == 0) { ctrl_w->n_pairs = 0u; ctrl_w->ent_off = ent_off; }
     }
     const bool odd = (ctrl->sort_passes & 1u) != 0;
     const uint32_t *sorted_ids = odd ? id_b : id_a, *sorted_rect8 = odd ? r8_b : r8_a;
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
                                                                  int bits_x, int tiles_y, const GaussRec *__restrict__ rec,
                                                                  const uint32_t *__restrict__ blk_off, uint32_t max_pairs,
                                                                  uint32_t *__restrict__ pkey, uint32_t *__restrict__ pval,
-                                                                 uint32_t draw_limit)
+                                                                 uint32_t draw_limit, Shard tsh, uint32_t *__restrict__ blk_entries)
 {
     __shared__ uint32_t scratch[8];
     __shared__ uint32_t s_off[EMIT_THREADS];   // exclusive pair offset of each gaussian inside the workgroup
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
 
     const unsigned long long base = blk_off[blockIdx.x];  // saturated at 2^32 - 1 by the scan: then nothing below is written
     const uint32_t culled_row = (uint32_t)tiles_y << bits_x;
+    uint32_t entries = 0;  // coarse: (gaussian, 16x16 tile) entries of the pairs this thread wrote = bits of their tile masks
     for (uint32_t j = tid; j < total; j += EMIT_THREADS) {
         // owner = last gaussian whose offset is <= j (zero-count gaussians share an offset with their successor)
         int lo = 0;
@@ -255,21 +259,24 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
         const unsigned long long o = base + j;
         if (o < (unsigned long long)max_pairs) {
             if (COARSE) {
-                // which of the cell's four tiles does the gaussian's tile rect cover?  The mask rides in the top four bits of the
-                // pair value.  Large rects are tested once per cell against the footprint (per tile it costs emit 20 us to
-                // spare the blend 3 % of its staging).
+                // which of the cell's four tiles does the gaussian's tile rect cover — and belong to this rank's tile rows (tsh)?
+                // The mask rides in the top four bits of the pair value; the blend of tile q of the cell takes the entries with
+                // bit q.  Large rects are tested once per cell against the footprint (per tile it costs emit 20 us to spare the
+                // blend 3 % of its staging).
                 const uint32_t f = s_fine[lo];
                 const int x0 = (int)(f & 255u), y0 = (int)((f >> 8) & 255u), x1 = (int)((f >> 16) & 255u), y1 = (int)(f >> 24);  // inclusive
                 uint32_t mask = 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int fx = 2 * tx + (q & 1), fy = 2 * ty + (q >> 1);
-                    mask |= (fx >= x0 && fx <= x1 && fy >= y0 && fy <= y1) ? 1u << q : 0u;
+                    const bool mine = tsh.step <= 1 || (fy >= tsh.begin && (fy - tsh.begin) % tsh.step == 0);
+                    mask |= (fx >= x0 && fx <= x1 && fy >= y0 && fy <= y1 && mine) ? 1u << q : 0u;
                 }
-                const bool hit = !tested || footprint_hits_rect(s_q0[lo], s_q1[lo], (float)(tx * 32), (float)(tx * 32 + 31),
-                                                                (float)(ty * 32), (float)(ty * 32 + 31));
+                const bool hit = mask != 0u && (!tested || footprint_hits_rect(s_q0[lo], s_q1[lo], (float)(tx * 32), (float)(tx * 32 + 31),
+                                                                               (float)(ty * 32), (float)(ty * 32 + 31)));
                 pkey[o] = (hit ? (uint32_t)ty << bits_x : culled_row) | (uint32_t)tx;
                 pval[o] = s_id[lo] | mask << COARSE_ID_BITS;
+                entries += hit ? (uint32_t)__popc(mask) : 0u;
             } else {
                 const bool hit = !tested || footprint_hits_rect(s_q0[lo], s_q1[lo], (float)(tx * 16), (float)(tx * 16 + 15),
                                                                 (float)(ty * 16), (float)(ty * 16 + 15));
@@ -277,6 +284,14 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
                 pval[o] = s_id[lo];
             }
         }
+    }
+    if (COARSE) {  // E = the sum of these partials, taken by gsr_read_stats (an atomic per workgroup here would serialise on one word).
+        // The workgroup's scanned offset (blk_off[blockIdx.x], read above by this workgroup alone) is no longer needed: its slot
+        // carries the partial.
+        __syncthreads();
+        uint32_t tot;
+        block_excl_scan_256(entries, scratch, &tot);
+        if (tid == 0) blk_entries[blockIdx.x] = tot;
     }
 }
 
@@ -312,76 +327,6 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t *__rest
     }
 }
 
-// Coarse binning, last step: every 32x32 cell's list (depth-ordered; value = gaussian id | tile mask << 28, the mask set at
-// emission from the gaussian's tile rect and, for large rects, the per-tile footprint test) -> the lists of its four 16x16
-// tiles.  One 1024-thread workgroup per cell, 4096 entries per trip.  An entry goes to tile q iff its mask has bit q and the
-// tile's row belongs to this shard; ballots + a wave scan over the 64 (sub-chunk, wave) counts make the compaction stable, so
-// every tile list is in depth order.  Tile q's list lives at [4 begin + q len, ... + count_q) of `pexp` (begin, len = the
-// cell's range): no global scan, the tile ranges are known on the spot.
-constexpr int EXPAND_THREADS = 1024, EXPAND_PER = 4;
-__global__ __launch_bounds__(EXPAND_THREADS) void pair_expand_kernel(const uint2 *__restrict__ cranges, const uint32_t *__restrict__ cval,
-                                                                     Shard sh, int ctiles_x, int tiles_x, int tiles_y,
-                                                                     uint32_t *__restrict__ pexp, uint2 *__restrict__ ranges, FrameCtrl *ctrl)
-{
-    constexpr int PER = EXPAND_PER, WAVES = EXPAND_THREADS / 64;
-    static_assert(PER * WAVES == 64, "one wave scans the (sub-chunk, wave) counts");
-    __shared__ uint32_t s_cnt[4][PER * WAVES];  // [tile q][sub-chunk j * WAVES + wave]: counts, then exclusive offsets
-    __shared__ uint32_t s_tot[4];
-    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint2 cr = cranges[c];
-    const uint32_t len = cr.y - cr.x;
-    if (len == 0) return;  // uniform
-    const int cy = c / ctiles_x, cx = c - cy * ctiles_x;
-    uint32_t okmask = 0;  // tiles of this cell that exist and belong to the shard
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int tx = 2 * cx + (q & 1), ty = 2 * cy + (q >> 1);
-        if (tx < tiles_x && ty < tiles_y && ty >= sh.begin && (ty - sh.begin) % sh.step == 0) okmask |= 1u << q;
-    }
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t out0 = 4u * cr.x;
-    uint32_t run[4] = {0u, 0u, 0u, 0u};
-    for (uint32_t base = 0; base < len; base += EXPAND_THREADS * PER) {
-        uint32_t v[PER];
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const uint32_t i = base + j * EXPAND_THREADS + tid;
-            v[j] = i < len ? cval[cr.x + i] : 0u;  // mask 0: goes nowhere
-        }
-        unsigned long long b[PER][4];
-#pragma unroll
-        for (int j = 0; j < PER; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                b[j][q] = __ballot(((v[j] >> COARSE_ID_BITS) & okmask) >> q & 1u);
-                if (lane == 0) s_cnt[q][j * WAVES + wave] = (uint32_t)__popcll(b[j][q]);
-            }
-        __syncthreads();
-        if (wave < 4) {  // wave q: exclusive scan of tile q's 64 counts, in list order (sub-chunk, wave)
-            const uint32_t x = s_cnt[wave][lane];
-            const uint32_t incl = wave_incl_scan(x);
-            s_cnt[wave][lane] = incl - x;
-            if (lane == 63) s_tot[wave] = incl;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t dst = out0 + (uint32_t)q * len + run[q];
-#pragma unroll
-            for (int j = 0; j < PER; ++j)
-                if ((b[j][q] >> lane) & 1ull)
-                    pexp[dst + s_cnt[q][j * WAVES + wave] + (uint32_t)__popcll(b[j][q] & lt_mask)] = v[j] & ((1u << COARSE_ID_BITS) - 1u);
-            run[q] += s_tot[q];
-        }
-        __syncthreads();
-    }
-    if (tid < 4 && ((okmask >> tid) & 1u)) {
-        const uint32_t o = out0 + (uint32_t)tid * len;
-        ranges[(2 * cy + (tid >> 1)) * tiles_x + 2 * cx + (tid & 1)] = make_uint2(o, o + run[tid]);
-    }
-    if (tid == 0) atomicAdd(&ctrl->n_pairs, run[0] + run[1] + run[2] + run[3]);
-}
-
 static int ceil_log2(int v)
 {
     int bits = 0;
@@ -389,7 +334,7 @@ static int ceil_log2(int v)
     return bits;
 }
 
-// Coarse binning when the packed rect exists (frames up to 4096 px) and the expanded lists stay indexable in 32 bits.
+// Coarse binning when the packed rect exists (frames up to 4096 px) and the gaussian ids leave four bits for the tile mask.
 // GSR_FINE_BINNING=1 forces the fine path (A/B timing, and the test that both build the same frame).
 TileKeying tile_keying(const Workspace &ws)
 {
@@ -408,10 +353,15 @@ TileKeying tile_keying(const Workspace &ws)
     return k;
 }
 
+// Coarse binning hands the blend the sorted CELL lists (values = gaussian id | tile mask << 28) and cranges[]; the blend of a tile
+// keeps the entries with its bit while it stages (blend.hip).  Round 2 expanded them into per-tile lists first (pair_expand_kernel:
+// 34 us, 122 MB of traffic, 16 B of workspace per pair slot); A/B in one process on the bench frame: bin + sort 0.375 -> 0.341 ms,
+// blend 0.553 -> 0.565 ms, frames and counters identical.
+bool blend_reads_cell_lists(const Workspace &ws) { return tile_keying(ws).coarse; }
+
 const uint32_t *tile_lists(const Workspace &ws)
 {
     const TileKeying tk = tile_keying(ws);
-    if (tk.coarse) return ws.pexp;
     if (ws.n <= 0 || ws.max_pairs <= 0) return ws.pval[0];
     return ws.pval[((tk.bits_x + tk.bits_y + 7) / 8) & 1];  // ping-pong parity of the tile sort's passes
 }
@@ -419,8 +369,9 @@ const uint32_t *tile_lists(const Workspace &ws)
 int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s)
 {
     const int n_tiles = ws.tiles_x * ws.tiles_y;
-    if (ws.n <= 0) {  // no count kernel to clear the ranges
+    if (ws.n <= 0) {  // no count kernel to clear the ranges (per tile, and per cell for a blend that reads the cell lists)
         GSR_HIP(hipMemsetAsync(ws.ranges, 0, sizeof(uint2) * (size_t)n_tiles, s));
+        GSR_HIP(hipMemsetAsync(ws.cranges, 0, sizeof(uint2) * (size_t)ws.ctiles_x * ws.ctiles_y, s));
         return GSR_OK;
     }
     const bool packed_rect = rect_fits_8bit(ws);
@@ -437,9 +388,11 @@ int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s)
     const int nblk = (int)((std::max<int64_t>(ws.n, n_tiles) + EMIT_THREADS - 1) / EMIT_THREADS);
     const int nblk_n = (int)((ws.n + EMIT_THREADS - 1) / EMIT_THREADS);
 #define GSR_COUNT(P, C) hipLaunchKernelGGL((pair_count_kernel<P, C>), dim3(nblk), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
-                                           ws.ctrl, ws.rect, C ? csh : sh, ws.blk_sum, ws.ranges, n_tiles, limit, ws.cranges, n_ctiles, ws.ctrl)
+                                           ws.ctrl, ws.rect, C ? csh : sh, ws.blk_sum, ws.ranges, n_tiles, limit, ws.cranges, n_ctiles, ws.ctrl, \
+                                           C ? (uint32_t)(reinterpret_cast<const char *>(ws.blk_sum) - reinterpret_cast<const char *>(ws.ctrl)) : 0u)
 #define GSR_EMIT(P, C) hipLaunchKernelGGL((pair_emit_kernel<P, C>), dim3(nblk_n), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
-                                          ws.ctrl, ws.rect, C ? csh : sh, tk.bits_x, tk.grid_y, ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0], limit)
+                                          ws.ctrl, ws.rect, C ? csh : sh, tk.bits_x, tk.grid_y, ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0], limit, \
+                                          sh, ws.blk_sum)
     if (tk.coarse) GSR_COUNT(true, true); else if (packed_rect) GSR_COUNT(true, false); else GSR_COUNT(false, false);
     hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, ws.blk_sum, nblk_n, ws.ctrl, cap);
     if (tk.coarse) GSR_EMIT(true, true); else if (packed_rect) GSR_EMIT(true, false); else GSR_EMIT(false, false);
@@ -455,9 +408,6 @@ int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s)
     const int grid = (int)std::min<int64_t>((ws.max_pairs + 1023) / 1024, 8192);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(grid), dim3(256), 0, s, ws.pkey[pbuf], n_sorted, tk.coarse ? ws.cranges : ws.ranges, tk.bits_x,
                        tk.grid_x, tk.grid_x * tk.grid_y, (uint32_t)grid * 256u);
-    if (tk.coarse)
-        hipLaunchKernelGGL(pair_expand_kernel, dim3(n_ctiles), dim3(EXPAND_THREADS), 0, s, ws.cranges, ws.pval[pbuf], sh, ws.ctiles_x,
-                           ws.tiles_x, ws.tiles_y, ws.pexp, ws.ranges, ws.ctrl);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

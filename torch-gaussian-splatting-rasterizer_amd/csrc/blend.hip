@@ -383,6 +383,82 @@ __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned l
           "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 }
 
+// ---- staging -----------------------------------------------------------------------------------------------------------------
+// A tile's depth-ordered list is either a range of per-tile entries (fine binning) or, with coarse binning, the list of its 32x32
+// cell filtered by the tile's bit of the mask each entry carries in its top four bits (binning.hip): the workgroup reads the
+// cell list 2 * THREADS entries at a time, keeps — in order, by ballot + wave counts — the ids with its bit in a small ring in
+// LDS, and stages THREADS of them per batch.  (Round 2 expanded the cell lists into tile lists in a kernel of its own: 34 us, a
+// write and a read of 61 MB per frame, 16 B of workspace per pair slot.)
+constexpr uint32_t LIST_ID_MASK = (1u << 28) - 1u;
+
+template <int THREADS>
+struct TileList {
+    static constexpr int WAVES = THREADS / 64, RING = 4 * THREADS;  // ring: < THREADS left over + 2 * THREADS read
+    uint32_t pos, end;    // cursor into the list / its end               } workgroup-uniform
+    uint32_t head, qlen;  // ring: first unread slot, entries in it       }
+    int bit;              // cell lists: 28 + the tile's index in its cell; -1: plain per-tile list
+};
+
+template <int THREADS>
+__device__ __forceinline__ TileList<THREADS> tile_list_of(const BlendArgs &a, int tile, int tx, int ty)
+{
+    TileList<THREADS> t;
+    uint2 r;
+    if (a.cell_lists) {
+        r = a.cranges[(ty >> 1) * a.ctiles_x + (tx >> 1)];
+        t.bit = 28 + (ty & 1) * 2 + (tx & 1);
+    } else {
+        r = a.ranges[tile];
+        t.bit = -1;
+    }
+    t.pos = r.x; t.end = r.y; t.head = 0; t.qlen = 0;
+    return t;
+}
+
+// One step of the staging loop, called by every thread after the loop's top barrier.  Returns -1: the ring was refilled, go round
+// again (the top barrier publishes it); 0: the list is exhausted; nb > 0: thread tid < nb takes the batch's tid-th gaussian, *id.
+template <int THREADS>
+__device__ __forceinline__ int tile_list_next(const BlendArgs &a, TileList<THREADS> &t, uint32_t *s_ring, uint32_t *s_wc, uint32_t *id)
+{
+    constexpr int WAVES = THREADS / 64, RING = TileList<THREADS>::RING;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (t.bit < 0) {
+        if (t.pos >= t.end) return 0;
+        const int nb = (int)min((uint32_t)THREADS, t.end - t.pos);
+        if (tid < nb) *id = a.pval[t.pos + tid];
+        t.pos += nb;
+        return nb;
+    }
+    if (t.qlen < (uint32_t)THREADS && t.pos < t.end) {  // refill: the next 2 * THREADS entries of the cell list, filtered in order
+        const uint32_t i0 = t.pos + tid, i1 = i0 + THREADS;
+        const uint32_t v0 = i0 < t.end ? a.pval[i0] : 0u, v1 = i1 < t.end ? a.pval[i1] : 0u;  // mask 0: nobody's
+        const bool f0 = (v0 >> t.bit) & 1u, f1 = (v1 >> t.bit) & 1u;
+        const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
+        if (lane == 0) { s_wc[wave] = (uint32_t)__popcll(b0); s_wc[WAVES + wave] = (uint32_t)__popcll(b1); }
+        __syncthreads();
+        uint32_t o0 = 0, tot0 = 0, o1 = 0, tot1 = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const uint32_t c0 = s_wc[w], c1 = s_wc[WAVES + w];
+            if (w < wave) { o0 += c0; o1 += c1; }
+            tot0 += c0; tot1 += c1;
+        }
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const uint32_t tail = t.head + t.qlen;
+        if (f0) s_ring[(tail + o0 + (uint32_t)__popcll(b0 & lt)) & (RING - 1)] = v0 & LIST_ID_MASK;
+        if (f1) s_ring[(tail + tot0 + o1 + (uint32_t)__popcll(b1 & lt)) & (RING - 1)] = v1 & LIST_ID_MASK;
+        t.qlen += tot0 + tot1;
+        t.pos += 2 * THREADS;
+        return -1;
+    }
+    if (t.qlen == 0) return 0;
+    const int nb = (int)min((uint32_t)THREADS, t.qlen);
+    if (tid < nb) *id = s_ring[(t.head + tid) & (RING - 1)];
+    t.head += nb;
+    t.qlen -= nb;
+    return nb;
+}
+
 // Tile launch order.  Group g = tile rows g, g+8, ... of the shard (one XCD's share).  One workgroup per
 // group bucket-sorts its tiles by list length, longest first (buckets = exponent + 3 mantissa bits of the
 // length, i.e. within 12.5 %): order[8*j + g] = j-th tile of group g.  Slots past the end of a group hold -1.
@@ -390,7 +466,8 @@ __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned l
 // Also leaves the longest list length in ctrl (stats).
 __global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict__ ranges, FrameCtrl *ctrl, int tiles_x,
                                                          int row_begin, int row_step, int rows, int slots_per_group,
-                                                         int *__restrict__ order, uint32_t stats_off)
+                                                         int *__restrict__ order, uint32_t stats_off, const uint2 *__restrict__ cranges,
+                                                         int ctiles_x)
 {
     constexpr int NB = 256;
     __shared__ uint32_t bucket_cnt[NB];
@@ -403,7 +480,11 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict
     for (int j = n + tid; j < slots_per_group; j += 256) order[8 * j + g] = -1;
     __syncthreads();
     auto tile_of = [&](int j) { return (row_begin + (g + 8 * (j / tiles_x)) * row_step) * tiles_x + (j % tiles_x); };
-    auto len_of = [&](int tile) { const uint2 r = ranges[tile]; return r.y - r.x; };
+    // cell lists (cranges != nullptr): the length of the tile's CELL list, an upper bound of what the tile will keep of it
+    auto len_of = [&](int tile) {
+        const uint2 r = cranges ? cranges[(tile / tiles_x >> 1) * ctiles_x + (tile % tiles_x >> 1)] : ranges[tile];
+        return r.y - r.x;
+    };
     // lengths < 2^24: float conversion is exact; bits >> 20 = exponent (8 bits) and 3 mantissa bits, monotone in len
     auto bucket_of = [&](uint32_t len) { return len == 0 ? (uint32_t)(NB - 1) : min((uint32_t)(NB - 2), (151u << 3) - (__float_as_uint((float)len) >> 20)); };
     uint32_t longest = 0;
@@ -432,11 +513,16 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict
 
 // The plain-C statement of the blend (GsrOptions.blend_impl = 1): one 256-thread workgroup per tile, wave = 8x8 quadrant, lane =
 // pixel.  The reference for the hand-scheduled kernel below, and what round 1 shipped.
+template <bool BF16ACC>  // GsrOptions.accum_dtype = 1: T and the colour sums live in bfloat16 (rounded to nearest even after every gaussian)
 __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
 {
+    auto acc_round = [](float &T, float &Cr, float &Cg, float &Cb) {
+        if (BF16ACC) { T = bf16_round(T); Cr = bf16_round(Cr); Cg = bf16_round(Cg); Cb = bf16_round(Cb); }
+    };
     __shared__ float4 srec[3][256];  // staged records, one plane per 16-B part: q0 at +0, q1 at +4096, q2 at +8192 bytes
     float4 *const s0 = srec[0], *const s1 = srec[1], *const s2 = srec[2];
     __shared__ int s_done;
+    __shared__ uint32_t s_ring[TileList<256>::RING], s_wc[2 * TileList<256>::WAVES];
 
     const int tile = a.order[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -452,27 +538,29 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
     const float fpx = (float)px, fpy = (float)py;
     const float qx0 = (float)qx, qx1 = (float)(qx + 7), qy0 = (float)qy, qy1 = (float)(qy + 7);
 
-    const uint2 range = a.ranges[tile];
+    TileList<256> list = tile_list_of<256>(a, tile, tx, ty);
     float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
     bool wave_done = false;
     uint32_t evaluated = 0;  // wave-uniform
     uint32_t fetched = 0;    // workgroup-uniform
     if (tid == 0) s_done = 0;
 
-    for (uint32_t batch = range.x; batch < range.y; batch += 256) {
-        __syncthreads();  // previous batch fully consumed (and s_done initialised)
+    for (;;) {
+        __syncthreads();  // previous batch fully consumed (and s_done initialised); a refilled ring published
         if (s_done == 4) break;  // uniform: every wave saturated
-        const uint32_t i = batch + tid;
-        fetched += min(256u, range.y - batch);
-        if (i < range.y) {
-            const GaussRec *r = a.rec + a.pval[i];
+        uint32_t id = 0;
+        const int nb = tile_list_next<256>(a, list, s_ring, s_wc, &id);
+        if (nb < 0) continue;
+        if (nb == 0) break;
+        fetched += (uint32_t)nb;
+        if (tid < nb) {
+            const GaussRec *r = a.rec + id;
             s0[tid] = r->q0;
             s1[tid] = r->q1;
             s2[tid] = r->q2;
         }
         __syncthreads();
         if (wave_done) continue;
-        const int nb = min(256u, range.y - batch);
         for (int chunk = 0; chunk < nb; chunk += 64) {
             const int e = chunk + lane;
             const bool hit = e < nb && footprint_hits_rect(s0[e], s1[e], qx0, qx1, qy0, qy1);
@@ -494,9 +582,12 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
                     const float4 ob = s2[k1];
                     asm volatile("" ::"v"(cb.w));
                     blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
+                    acc_round(T, Cr, Cg, Cb);
                     blend_one(gb, cb, ob, fpx, fpy, T, Cr, Cg, Cb);
+                    acc_round(T, Cr, Cg, Cb);
                 } else {
                     blend_one(ga, ca, oa, fpx, fpy, T, Cr, Cg, Cb);
+                    acc_round(T, Cr, Cg, Cb);
                 }
             }
             if (__all(T <= a.early_T)) {
@@ -541,6 +632,7 @@ __global__ __launch_bounds__(256 / QPW, 8) void blend_walk_kernel(BlendArgs a)
     float4 *const s0 = srec[0], *const s1 = srec[1], *const s2 = srec[2];
     const unsigned lds_rec = (unsigned)(size_t)&srec[0][0];  // LDS byte address: the low half of the flat pointer
     __shared__ int s_done;
+    __shared__ uint32_t s_ring[TileList<THREADS>::RING], s_wc[2 * WAVES];
 
     const int tile = a.order[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -559,7 +651,7 @@ __global__ __launch_bounds__(256 / QPW, 8) void blend_walk_kernel(BlendArgs a)
     const float xa0 = (float)qx, xa1 = (float)(qx + 7), xb0 = (float)(qx + 8), xb1 = (float)(qx + 15);
     const float qy0 = (float)qy, qy1 = (float)(qy + 7);
 
-    const uint2 range = a.ranges[tile];
+    TileList<THREADS> list = tile_list_of<THREADS>(a, tile, tx, ty);
     float TA = 1.0f, CrA = 0.0f, CgA = 0.0f, CbA = 0.0f;
     float TB = 1.0f, CrB = 0.0f, CgB = 0.0f, CbB = 0.0f;
     bool doneA = false, doneB = QPW == 1;  // wave-uniform: quadrant saturated (B does not exist when QPW = 1)
@@ -567,20 +659,22 @@ __global__ __launch_bounds__(256 / QPW, 8) void blend_walk_kernel(BlendArgs a)
     uint32_t fetched = 0;                  // workgroup-uniform
     if (tid == 0) s_done = 0;
 
-    for (uint32_t batch = range.x; batch < range.y; batch += BATCH) {
-        __syncthreads();  // previous batch fully consumed (and s_done initialised)
+    for (;;) {
+        __syncthreads();  // previous batch fully consumed (and s_done initialised); a refilled ring published
         if (s_done == WAVES) break;  // uniform: every wave saturated
-        const uint32_t i = batch + tid;
-        fetched += min((uint32_t)BATCH, range.y - batch);
-        if (i < range.y) {
-            const GaussRec *r = a.rec + a.pval[i];
+        uint32_t id = 0;
+        const int nb = tile_list_next<THREADS>(a, list, s_ring, s_wc, &id);
+        if (nb < 0) continue;
+        if (nb == 0) break;
+        fetched += (uint32_t)nb;
+        if (tid < nb) {
+            const GaussRec *r = a.rec + id;
             s0[tid] = r->q0;
             s1[tid] = r->q1;
             s2[tid] = r->q2;
         }
         __syncthreads();
         if (doneA && doneB) continue;
-        const int nb = min((uint32_t)BATCH, range.y - batch);
         for (int chunk = 0; chunk < nb; chunk += 64) {
             const int e = chunk + lane;
             FootprintClass fa = {false, false}, fb = {false, false};
@@ -646,6 +740,9 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
 {
     BlendArgs a;
     a.ranges = ws.ranges;
+    a.cranges = ws.cranges;
+    a.ctiles_x = ws.ctiles_x;
+    a.cell_lists = blend_reads_cell_lists(ws) ? 1 : 0;
     a.pval = lists;
     a.rec = ws.rec;
     a.out = out_image;
@@ -667,8 +764,10 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     a.order = ws.tile_order;
     hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(256), 0, s, ws.ranges, ws.ctrl, a.tiles_x, a.row_begin, a.row_step, a.rows,
                        slots_per_group, ws.tile_order,
-                       (uint32_t)(reinterpret_cast<const char *>(ws.blend_stats) - reinterpret_cast<const char *>(ws.ctrl)));
-    if (opts.blend_impl == 1) hipLaunchKernelGGL(blend_kernel, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
+                       (uint32_t)(reinterpret_cast<const char *>(ws.blend_stats) - reinterpret_cast<const char *>(ws.ctrl)),
+                       a.cell_lists ? ws.cranges : nullptr, ws.ctiles_x);
+    if (opts.accum_dtype == 1) hipLaunchKernelGGL(blend_kernel<true>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
+    else if (opts.blend_impl == 1) hipLaunchKernelGGL(blend_kernel<false>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     else if (a.rows * a.tiles_x >= BLEND_HALF_MIN_TILES) hipLaunchKernelGGL(blend_walk_kernel<2>, dim3(8u * (unsigned)slots_per_group), dim3(128), 0, s, a);
     else hipLaunchKernelGGL(blend_walk_kernel<1>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     GSR_HIP(hipGetLastError());
@@ -702,6 +801,24 @@ __global__ __launch_bounds__(1024) void blend_stats_kernel(FrameCtrl *ctrl, size
         for (int w = 0; w < 16; ++w) { ev += part[0][w]; fe += part[1][w]; }
         ctrl->wave_entries = ev;
         ctrl->fetched_entries = fe;
+    }
+    // E, when the blend reads the cell lists directly (binning.hip): the emit workgroups' partial counts, one per 256 depth-sorted gaussians
+    const uint32_t eoff = ctrl->ent_off;
+    const size_t nblk = ((size_t)ctrl->n_visible + EMIT_THREADS - 1) / EMIT_THREADS;
+    if (eoff >= sizeof(FrameCtrl) && (size_t)eoff + 4 * nblk <= workspace_bytes) {
+        __syncthreads();
+        const uint32_t *pe = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(ctrl) + eoff);
+        unsigned long long e = 0;
+        for (size_t i = threadIdx.x; i < nblk; i += 1024) e += pe[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) e += __shfl_xor(e, d, 64);
+        if ((threadIdx.x & 63) == 0) part[0][threadIdx.x >> 6] = e;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            e = 0;
+            for (int w = 0; w < 16; ++w) e += part[0][w];
+            ctrl->n_pairs = e > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e;
+        }
     }
 }
 

@@ -5,8 +5,11 @@
 namespace gsr {
 
 struct BlendArgs {
-    const uint2 *ranges;
-    const uint32_t *pval;
+    const uint2 *ranges;  // [tiles] per-tile lists (fine binning)
+    const uint2 *cranges; // [cells] cell_lists: the 32x32-cell lists; the tile's entries are those with its bit in the top four
+    int ctiles_x;
+    int cell_lists;
+    const uint32_t *pval; // the lists: gaussian ids (cell_lists: | tile mask << 28)
     const GaussRec *rec;
     void *out;            // float32, or bfloat16 when out_bf16
     float *out_T;
@@ -20,6 +23,13 @@ struct BlendArgs {
     int out_bf16;
     float early_T;
 };
+
+// float -> the nearest bfloat16 (ties to even), as a float.  Values are finite.
+__device__ __forceinline__ float bf16_round(float x)
+{
+    const uint32_t u = __float_as_uint(x);
+    return __uint_as_float((u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u);
+}
 
 // One pixel's colour into the frame.  bfloat16 = the upper half of the float, rounded to nearest even (values are finite).
 __device__ __forceinline__ void store_rgb(const BlendArgs &a, size_t o, float r, float g, float b)

@@ -30,6 +30,8 @@ struct FrameCtrl {
     uint32_t sort_bits_rest; //   after the first.  Written by the pass-0 rowscan (with sort_passes).
     uint32_t n_cpairs;       // coarse binning: 32x32-cell pairs that survive the sort's drop (count of the coarse ranges pass)
     uint32_t n_records;      // multi-GPU shard: records entering the depth sort (= this rank's visible gaussians; preprocess.hip)
+    uint32_t ent_off;        // coarse binning without expansion: byte offset (from this struct) of the emit workgroups' partial counts
+                             // of tile-list entries; gsr_read_stats totals them into n_pairs.  0: n_pairs is already final.
     uint32_t depth_key_max;  // maximum of the frame's valid depth keys (pass-0 histogram).  Cleared with the frame AND by the pass-0
                              // rowscan once consumed (gsr_bin_sort may be repeated on one gsr_preprocess).
     // ---- everything below survives the per-frame clear of a frame rendered with GsrOptions.keep_flags (and of the later views
@@ -71,7 +73,6 @@ struct Workspace {
     uint32_t *pval[2];    // [max_pairs] gaussian ids
     uint2 *ranges;        // [tiles]
     uint2 *cranges;       // [ctiles]  coarse binning: [begin, end) of every 32x32 cell's list in the sorted pair array
-    uint32_t *pexp;       // [4 * max_pairs]  coarse binning: the per-tile lists, expanded from the cell lists
     int *tile_order;      // [8 * ceil(tiles_y/8) * tiles_x] blend launch order
     uint32_t *blend_stats; // [tile_order slots][BLEND_STAT_WORDS] per-workgroup counters: plain stores, no atomics (40 k
                           // same-address atomics per frame put a 0.45 ms floor under the blend kernel)
@@ -119,14 +120,13 @@ int launch_pair_sort(const Workspace &ws, int in_buf, const uint32_t *n_dev, int
 struct TileKeying {
     int bits_x, bits_y;   // of the grid the pairs are generated on: tiles, or 32x32 cells when `coarse`
     uint32_t drop_from;
-    bool coarse;          // pairs are generated and sorted per 32x32 cell, then expanded into the tile lists (binning.hip)
+    bool coarse;          // pairs are generated and sorted per 32x32 cell; the blend filters the cell lists by tile (binning.hip)
     int grid_x, grid_y;
 };
 TileKeying tile_keying(const Workspace &ws);
 inline bool rect_fits_8bit(const Workspace &ws) { return ws.tiles_x <= 256 && ws.tiles_y <= 256; }
-// Can this workspace bin per 32x32 cell (binning.hip)?  Needs the packed rect, pair values of 28 id bits + 4 mask bits, and the
-// expanded lists (4 words per pair slot) indexable in 32 bits.  Decides the workspace LAYOUT (pexp), so it depends on nothing else.
-inline bool coarse_capable(const Workspace &ws) { return rect_fits_8bit(ws) && ws.max_pairs <= (int64_t)0x3FFFFFFF && ws.n <= ((int64_t)1 << 28); }
+// Can this frame bin per 32x32 cell (binning.hip)?  Needs the packed rect and pair values of 28 id bits + 4 mask bits.
+inline bool coarse_capable(const Workspace &ws) { return rect_fits_8bit(ws) && ws.n <= ((int64_t)1 << 28); }
 // A multi-GPU shard's preprocess (preprocess.hip) hands the depth sort a compact list of (key, id, rect) records of the rank's
 // visible gaussians instead of one key per gaussian.  Progressive frames (draw_limit) rank ALL gaussians the reference
 // draws, so they take the whole-frame path.
@@ -139,7 +139,8 @@ inline bool shard_compact(const GsrOptions &o)
 // Stage 2b: pairs of the depth-sorted gaussians -> per-tile depth-ordered lists + ranges[] (count, scan, emit, sort, ranges,
 // and with coarse binning the expansion).
 int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s);
-const uint32_t *tile_lists(const Workspace &ws);  // the array ranges[] indexes after launch_binning (gaussian ids)
+const uint32_t *tile_lists(const Workspace &ws);  // the array ranges[] / cranges[] index after launch_binning (gaussian ids [| tile mask << 28])
+bool blend_reads_cell_lists(const Workspace &ws);  // coarse binning: the blend filters the 32x32-cell lists by tile bit itself
 int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, const uint32_t *lists, void *out_image,
                  float *out_T, hipStream_t s);
 int launch_blend_stats(FrameCtrl *ctrl, size_t workspace_bytes, hipStream_t s);

@@ -6,7 +6,8 @@
 //   radix_clear        zero the per-wave digit counters and the peer masks
 //   radix_rank         rank[r] = number of EARLIER records of this wave with the same digit (through LDS peer masks)
 //   radix_tile_layout  per-wave exclusive bases + start of every digit inside the reordered tile
-//   radix_reorder      records -> LDS in digit order; the caller then writes digit runs out contiguously
+//   radix_positions    where every record lands in the reordered tile; the caller then moves ONE array at a time through the
+//                      tile buffer (records -> LDS in digit order -> digit runs written out contiguously)
 #pragma once
 #include "gsr_internal.h"
 
@@ -47,16 +48,18 @@ __device__ __forceinline__ bool resolve_pass(const PassSpec &a, const FrameCtrl 
 // owns digit t in the per-digit steps.  256 threads / 4096 records for the pair sort (8-bit digits and fewer), 512 threads /
 // 8192 records for the depth sort's 9-bit digits: with twice the digit values a 4096-record tile's runs halve (8 records =
 // 32 B per array, measured +35 % per pass); doubling the tile keeps the runs at 16 records and the table reads per record equal.
+// LDS budget: the arrays of a record (key, value, second value) pass through ONE tile-sized buffer one after the other instead of
+// each having its own (three barriers more per tile): 52 KB instead of 116 KB for the depth sort's 512-thread tiles, so that three
+// workgroups share a CU instead of one — the passes are bound by the latency of a tile's dependent phases (load, rank, layout,
+// reorder, store), not by any pipe, and with one workgroup per CU a 410-tile pass ran as two rounds of 256 + 154.
 template <int THREADS, int ITEMS, bool HAS_V2>
 struct RadixTileSmem {
     static constexpr int TILE = THREADS * ITEMS, WAVES = THREADS / 64, DIGITS = THREADS;
     static_assert(THREADS == 256 || THREADS == 512, "digit d is owned by thread d");
-    static_assert(WAVES * DIGITS * 8 <= TILE * 4, "the peer masks live in skey until the reorder");
+    static_assert(WAVES * DIGITS * 8 <= TILE * 4, "the peer masks live in the tile buffer until the reorder");
     uint32_t wave_cnt[WAVES][DIGITS];  // per-wave digit counts, then per-wave exclusive bases
     uint32_t tile_start[DIGITS];       // start of digit d inside the reordered tile
-    uint32_t skey[TILE];
-    uint32_t sval[TILE];
-    uint32_t sval2[HAS_V2 ? TILE : 1];
+    uint32_t buf[TILE];                // peer masks while ranking, then one array of the tile at a time in digit order
     uint32_t scratch[2 * WAVES];
     uint32_t n_valid;
 };
@@ -66,7 +69,7 @@ __device__ __forceinline__ void radix_clear(RadixTileSmem<THREADS, ITEMS, HAS_V2
 {
     constexpr int WAVES = THREADS / 64;
     uint32_t *wc = &sm.wave_cnt[0][0];
-    unsigned long long *pm = reinterpret_cast<unsigned long long *>(sm.skey);
+    unsigned long long *pm = reinterpret_cast<unsigned long long *>(sm.buf);
 #pragma unroll
     for (int i = 0; i < WAVES; ++i) {
         wc[i * THREADS + threadIdx.x] = 0u;
@@ -85,7 +88,7 @@ template <int THREADS, int ITEMS, bool HAS_V2, typename DigitOf>
 __device__ __forceinline__ void radix_rank(RadixTileSmem<THREADS, ITEMS, HAS_V2> &sm, DigitOf dig, uint32_t (&rank)[ITEMS])
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long *pm = reinterpret_cast<unsigned long long *>(sm.skey) + wave * THREADS;  // skey is not live until the reorder
+    unsigned long long *pm = reinterpret_cast<unsigned long long *>(sm.buf) + wave * THREADS;  // the tile buffer is not live until the reorder
     uint32_t *wc = sm.wave_cnt[wave];
     const unsigned long long my_bit = 1ull << lane, lt_mask = my_bit - 1ull;
     // GROUP rounds at a time: all their LDS traffic is issued back to back (three waits per group instead of per round)
@@ -140,24 +143,28 @@ __device__ __forceinline__ void radix_tile_layout(RadixTileSmem<THREADS, ITEMS, 
     if (threadIdx.x == 0) sm.n_valid = total;
 }
 
-// Records -> LDS in digit order (stable).  Needs the tables of radix_tile_layout behind a barrier; the caller adds a
-// barrier before reading skey/sval back.
+// After radix_tile_layout + a barrier: rank[r] (rank among the wave's earlier records of the same digit) -> the record's position
+// in the reordered tile (stable), RADIX_NO_DIGIT stays.  In place.
 template <int THREADS, int ITEMS, bool HAS_V2, typename DigitOf>
-__device__ __forceinline__ void radix_reorder(RadixTileSmem<THREADS, ITEMS, HAS_V2> &sm, DigitOf dig, const uint32_t (&rank)[ITEMS],
-                                              const uint32_t (&key)[ITEMS], const uint32_t (&val)[ITEMS],
-                                              const uint32_t (&val2)[HAS_V2 ? ITEMS : 1])
+__device__ __forceinline__ void radix_positions(const RadixTileSmem<THREADS, ITEMS, HAS_V2> &sm, DigitOf dig, uint32_t (&rank)[ITEMS])
 {
     const int wave = threadIdx.x >> 6;
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         if (rank[r] != RADIX_NO_DIGIT) {
             const uint32_t d = dig(r);
-            const uint32_t pos = sm.tile_start[d] + sm.wave_cnt[wave][d] + rank[r];
-            sm.skey[pos] = key[r];
-            sm.sval[pos] = val[r];
-            if (HAS_V2) sm.sval2[pos] = val2[r];
+            rank[r] = sm.tile_start[d] + sm.wave_cnt[wave][d] + rank[r];
         }
     }
+}
+
+// One array of the tile -> the tile buffer, in digit order.  The caller brackets it with barriers.
+template <int THREADS, int ITEMS, bool HAS_V2>
+__device__ __forceinline__ void radix_stage(RadixTileSmem<THREADS, ITEMS, HAS_V2> &sm, const uint32_t (&pos)[ITEMS], const uint32_t (&v)[ITEMS])
+{
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r)
+        if (pos[r] != RADIX_NO_DIGIT) sm.buf[pos[r]] = v[r];
 }
 
 }  // namespace gsr

@@ -140,8 +140,11 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t *__restrict
     if (threadIdx.x == 0) ctrl->digit_tot[blockIdx.x] = carry;
 }
 
+// Register budget: two 512-thread workgroups per CU (128 VGPRs; one before: 119 KB of LDS) — depth-sort scatters 54 / 32 us ->
+// 49 / 28 us on the bench frame.  The 256-thread pair sort stays at four per CU: pressed into 96 VGPRs for a fifth it spills
+// and takes 53 instead of 37 us.
 template <int THREADS, bool DROP, int ITEMS, bool HAS_V2, bool INDEX_VALS>
-__global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
+__global__ __launch_bounds__(THREADS, 4) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint32_t *__restrict__ vals2_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t *__restrict__ vals2_out, const uint32_t *n_dev,
     uint32_t n_bound, PassSpec ps, const FrameCtrl *ctrl, const uint32_t *__restrict__ hist, int hist_blocks, uint32_t *n_out)
@@ -162,25 +165,23 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     radix_clear(sm);
     __syncthreads();
 
-    uint32_t key[ITEMS], val[ITEMS], val2[HAS_V2 ? ITEMS : 1], rank[ITEMS];
-    if (n - base >= (uint32_t)TILE) {  // full tile (all but the last workgroup): unguarded loads, all in flight together
+    // keys first; the payloads are loaded when their turn at the tile buffer comes (their loads fly while the previous array
+    // goes out), so that at most four 16-register arrays are live at once
+    uint32_t key[ITEMS], rank[ITEMS];
+    const bool full = n - base >= (uint32_t)TILE;  // all but the last workgroup: unguarded loads, all in flight together
+    auto load = [&](const uint32_t *__restrict__ src, uint32_t (&v)[ITEMS], uint32_t fill) {
+        if (full) {
 #pragma unroll
-        for (int r = 0; r < ITEMS; ++r) {
-            const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
-            key[r] = keys_in[idx];
-            val[r] = INDEX_VALS ? idx : vals_in[idx];  // INDEX_VALS: the payload is the element's index, nothing to load
-            if (HAS_V2) val2[r] = vals2_in[idx];
-        }
-    } else {
+            for (int r = 0; r < ITEMS; ++r) v[r] = src[base + wave * (64 * ITEMS) + r * 64 + lane];
+        } else {
 #pragma unroll
-        for (int r = 0; r < ITEMS; ++r) {
-            const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
-            const bool in = idx < n;
-            key[r] = in ? keys_in[idx] : KEY_INVALID;
-            val[r] = INDEX_VALS ? idx : (in ? vals_in[idx] : 0u);
-            if (HAS_V2) val2[r] = in ? vals2_in[idx] : 0u;
+            for (int r = 0; r < ITEMS; ++r) {
+                const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
+                v[r] = idx < n ? src[idx] : fill;
+            }
         }
-    }
+    };
+    load(keys_in, key, KEY_INVALID);
     auto dig = [&](int r) -> uint32_t {
         const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
         const bool valid = (idx < n) && (!DROP || key[r] < ps.drop_from);
@@ -199,17 +200,47 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     }
     __syncthreads();
 
-    radix_reorder(sm, dig, rank, key, val, val2);
+    radix_positions(sm, dig, rank);  // rank[] is now the position inside the reordered tile
+    uint32_t val[ITEMS];
+    if (INDEX_VALS) {  // the payload is the element's index: nothing to load
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) val[r] = base + wave * (64 * ITEMS) + r * 64 + lane;
+    } else {
+        load(vals_in, val, 0u);
+    }
+    // keys through the tile buffer; every output slot's global position is fixed on the way and kept for the payloads
+    radix_stage(sm, rank, key);
     __syncthreads();
-
     const uint32_t nvalid = sm.n_valid;
-    for (uint32_t i = tid; i < nvalid; i += THREADS) {
-        const uint32_t k = sm.skey[i];
-        const uint32_t d = ((k - ps.key_base) >> shift) & mask;
-        const uint32_t gpos = digit_base[d] + (i - sm.tile_start[d]);
-        keys_out[gpos] = k;
-        vals_out[gpos] = sm.sval[i];
-        if (HAS_V2) vals2_out[gpos] = sm.sval2[i];
+    uint32_t gpos[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)k * THREADS;
+        if (i < nvalid) {
+            const uint32_t kk = sm.buf[i];
+            const uint32_t d = ((kk - ps.key_base) >> shift) & mask;
+            gpos[k] = digit_base[d] + (i - sm.tile_start[d]);
+            keys_out[gpos[k]] = kk;
+        }
+    }
+    __syncthreads();
+    radix_stage(sm, rank, val);
+    if constexpr (HAS_V2) load(vals2_in, val, 0u);  // val is staged: its registers take the second payload
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)k * THREADS;
+        if (i < nvalid) vals_out[gpos[k]] = sm.buf[i];
+    }
+    if constexpr (HAS_V2) {
+        __syncthreads();
+        radix_stage(sm, rank, val);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)k * THREADS;
+            if (i < nvalid) vals2_out[gpos[k]] = sm.buf[i];
+        }
     }
 }
 

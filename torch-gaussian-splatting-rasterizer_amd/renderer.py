@@ -84,7 +84,7 @@ def make_camera(qvec, tvec, fx_full: float, fy_full: float, cam_width: int, cam_
 
 def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_row_begin: int = 0, tile_row_step: int = 1,
                  output_layout: int = 0, no_footprint_cull: bool = False, blend_impl: int = 0, draw_limit: int = 0,
-                 output_bf16: bool = False, depth_sort_passes: int = 0, keep_flags: bool = False) -> GsrOptions:
+                 output_bf16: bool = False, depth_sort_passes: int = 0, keep_flags: bool = False, accum_bf16: bool = False) -> GsrOptions:
     o = _lib.default_options()
     o.reference_compat = 1 if reference_compat else 0
     o.early_out_T = float(early_out_T)
@@ -96,6 +96,7 @@ def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_r
     o.draw_limit = int(draw_limit)
     o.output_dtype = 1 if output_bf16 else 0  # frame stored as bfloat16; accumulation stays fp32
     o.depth_sort_passes = int(depth_sort_passes)  # 0: no bound (Rasterizer.render / render_batch fill in what the frames' counters have taught them)
+    o.accum_dtype = 1 if accum_bf16 else 0        # configs[2] as worded: bf16 accumulators (measurement option, plain-C kernel)
     o.keep_flags = 1 if keep_flags else 0         # Rasterizer.enqueue sets it itself for the frames after the first since the last stats()
     return o
 
@@ -115,7 +116,7 @@ class Rasterizer:
         # are read): passed as GsrOptions.depth_sort_passes so that the passes a frame does not need are not even enqueued
         self.sort_passes = 0
         self._ws: Optional[torch.Tensor] = None
-        self._rendered = False     # a frame has run on the workspace
+        self._last_empty = False   # the last enqueue was a shard without tile rows: no kernel ran, its counters are all zero
         self._chained = False      # frames have been enqueued since the last stats(): the next one keeps their overflow record
         self._ws_key = None
         self.last_stats: Optional[Dict[str, int]] = None
@@ -132,7 +133,7 @@ class Rasterizer:
             # running key maximum (the one word libgsr carries from frame to frame) starts at 0 instead of garbage
             self._ws[: min(4096, nbytes)].zero_()
             self._ws_key = key
-            self._rendered = self._chained = False
+            self._chained = self._last_empty = False
         return self._ws
 
     def _out_shape(self, cam: GsrCamera, opts: GsrOptions):
@@ -171,6 +172,7 @@ class Rasterizer:
         elif tuple(out.shape) != shape or out.dtype != dtype or not out.is_contiguous() or not out.is_cuda:
             raise ValueError(f"out must be a contiguous {dtype} CUDA tensor of shape {shape}")
         if out.numel() == 0:  # a shard that owns no tile row (more ranks than tile rows): nothing to render
+            self._last_empty = True
             return out
         if self._chained and not opts.keep_flags:
             opts = GsrOptions.from_buffer_copy(opts)
@@ -179,13 +181,13 @@ class Rasterizer:
         tptr = final_T.data_ptr() if final_T is not None else None
         check(lib.gsr_render_forward(C.byref(sc), C.byref(cam), C.byref(opts), self.max_pairs, ws.data_ptr(), ws.numel(),
                                      out.data_ptr(), tptr, _stream_ptr(self.scene.device)))
-        self._rendered = self._chained = True
+        self._chained, self._last_empty = True, False
         return out
 
     def stats(self) -> Dict[str, int]:
         """Counters of the last enqueued frame (synchronises the stream); its overflow record covers every frame since the
         previous stats().  Raises GsrPairOverflow / GsrSortPasses when one of them exceeded a bound."""
-        if not self._rendered:  # nothing has run on this workspace (only empty shards so far): nothing to read
+        if self._ws is None or self._last_empty:  # no workspace yet / an empty shard: no kernel ran, nothing to read
             self.last_stats = {k: 0 for k, _ in GsrStats._fields_ if not k.startswith("_")}
             return self.last_stats
         st = GsrStats()
@@ -258,7 +260,7 @@ class Rasterizer:
             o.keep_flags = 0  # view 0 clears the record, libgsr chains the rest: the counters then speak for every view
             check(lib.gsr_render_batch(C.byref(sc), arr, len(cams), C.byref(o), self.max_pairs, ws.data_ptr(), ws.numel(),
                                        out.data_ptr(), H * W * 3, _stream_ptr(self.scene.device)))
-            self._rendered = self._chained = True
+            self._chained, self._last_empty = True, False
             try:
                 self.stats()
                 return out
@@ -382,7 +384,7 @@ class FramesInFlight:
                                              out.data_ptr(), H * W * 3))
             used = min(n, len(cams))
             for r in self.rasterizers[:used]:
-                r._rendered = r._chained = True
+                r._chained, r._last_empty = True, False
             need, short = 0, False
             for k in range(used):
                 try:
