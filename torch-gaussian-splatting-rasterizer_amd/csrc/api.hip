@@ -45,7 +45,7 @@ size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max
     ws->ctiles_x = (ws->tiles_x + 1) / 2;
     ws->ctiles_y = (ws->tiles_y + 1) / 2;
     // row stride of the histogram table: tiles of the depth sort, tiles of the pair sort
-    ws->hist_blocks = (int)std::max((nn + DEPTH_SORT_THREADS * DEPTH_SORT_ITEMS - 1) / (DEPTH_SORT_THREADS * DEPTH_SORT_ITEMS),
+    ws->hist_blocks = (int)std::max((nn + DEPTH_SORT_THREADS * DEPTH_SORT_ITEMS_SHARD - 1) / (DEPTH_SORT_THREADS * DEPTH_SORT_ITEMS_SHARD),
                                     (np + PAIR_SORT_THREADS * PAIR_SORT_ITEMS - 1) / (PAIR_SORT_THREADS * PAIR_SORT_ITEMS));
     ws->ctrl = static_cast<FrameCtrl *>(take(sizeof(FrameCtrl)));
     ws->rec = static_cast<GaussRec *>(take(sizeof(GaussRec) * nn));

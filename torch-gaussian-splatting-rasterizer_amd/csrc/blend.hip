@@ -29,6 +29,7 @@
 // + 8 per tile range.  The kernel is bound on-chip, not by HBM: per evaluated (quadrant, entry) ~15 VALU issues incl. one
 // quarter-rate v_exp_f32, and the record's three wave-wide LDS broadcast reads (10 LDS cycles).  bench.py reports the HBM
 // fraction (the contract figure) and, from the committed PMC passes, the VALU issue and LDS busy fractions.
+#include <cstdlib>
 #include "gsr_internal.h"
 #include "blend_args.h"
 #include "footprint.h"
@@ -383,6 +384,362 @@ __device__ __forceinline__ void blend_walk2_asm(unsigned long long m, unsigned l
           "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 }
 
+// The PIPELINED one-quadrant walk, for launches that cannot fill the machine (a multi-GPU rank's shard: ~4 waves per SIMD, where a
+// wave's walk runs at its own latency — tools/walk_latency.hip: 77 ns per record alone on a SIMD, ~7 cycles per instruction of one
+// serial stream).  The stream is software-pipelined by one record: alpha of record k+1 (8 instructions in two independent
+// sub-chains, v_exp_f32 last) is computed BEFORE record k is applied (v_cmpx + 5 masked updates), so the transcendental's latency
+// and the quadratic's dependent chain sit under the previous record's update.  Three register sets of 12 (record 10, p, alpha)
+// rotate: record k is applied while k+1 is evaluated and k+2's LDS reads are in flight.  The same operations on the same values in
+// the same per-pixel order: bit-identical to blend_kernel (tests).  Needs 96 VGPRs (v54-v95 named here): the kernel variant that
+// uses it is launched only where 5 waves per SIMD hold the whole grid.  Generated by tools/gen_blend_walk.py pipelined.
+template <int PLANE>
+__device__ __forceinline__ void blend_walk1p_asm(unsigned long long m, unsigned long long fa, unsigned lds_chunk, float fpx, float fpy,
+                                                 float &T, float &Cr, float &Cg, float &Cb)
+{
+    int ia, ib, ic;
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_ff1_i32_b64 %[ia], %[m]\n\t"
+        "s_bitset0_b64 %[m], %[ia]\n\t"
+        "v_lshl_add_u32 v90, %[ia], 4, %[base]\n\t"
+        "ds_read_b64 v[54:55], v90\n\t"
+        "ds_read_b128 v[56:59], v90 offset:%[p1]\n\t"
+        "ds_read_b128 v[60:63], v90 offset:%[p2]\n\t"
+        "s_cmp_eq_u64 %[m], 0\n\t"
+        "s_cbranch_scc1 30f\n\t"
+        "s_ff1_i32_b64 %[ib], %[m]\n\t"
+        "s_bitset0_b64 %[m], %[ib]\n\t"
+        "v_lshl_add_u32 v90, %[ib], 4, %[base]\n\t"
+        "ds_read_b64 v[66:67], v90\n\t"
+        "ds_read_b128 v[68:71], v90 offset:%[p1]\n\t"
+        "ds_read_b128 v[72:75], v90 offset:%[p2]\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        "v_sub_f32 v91, v55, %[fpy]\n\t"
+        "v_sub_f32 v93, v54, %[fpx]\n\t"
+        "v_mul_f32 v92, v58, v91\n\t"
+        "v_mul_f32 v94, v56, v93\n\t"
+        "v_fma_f32 v92, v92, v91, v60\n\t"
+        "v_fma_f32 v94, v57, v91, v94\n\t"
+        "v_fma_f32 v64, v93, v94, v92\n\t"
+        "v_exp_f32 v65, v64\n\t"
+        "10:\n\t"
+        "s_cmp_eq_u64 %[m], 0\n\t"
+        "s_cbranch_scc1 20f\n\t"
+        "s_ff1_i32_b64 %[ic], %[m]\n\t"
+        "s_bitset0_b64 %[m], %[ic]\n\t"
+        "v_lshl_add_u32 v90, %[ic], 4, %[base]\n\t"
+        "ds_read_b64 v[78:79], v90\n\t"
+        "ds_read_b128 v[80:83], v90 offset:%[p1]\n\t"
+        "ds_read_b128 v[84:87], v90 offset:%[p2]\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        "v_sub_f32 v91, v67, %[fpy]\n\t"
+        "v_sub_f32 v93, v66, %[fpx]\n\t"
+        "v_mul_f32 v92, v70, v91\n\t"
+        "v_mul_f32 v94, v68, v93\n\t"
+        "v_fma_f32 v92, v92, v91, v72\n\t"
+        "v_fma_f32 v94, v69, v91, v94\n\t"
+        "v_fma_f32 v76, v93, v94, v92\n\t"
+        "v_exp_f32 v77, v76\n\t"
+        "s_bitcmp1_b64 %[fa], %[ia]\n\t"
+        "s_cbranch_scc0 40f\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v65\n\t"
+        "v_mul_f32 v95, %[T], v65\n\t"
+        "v_fma_f32 %[Cr], v95, v61, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v62, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v63, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v65, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "41:\n\t"
+        "11:\n\t"
+        "s_cmp_eq_u64 %[m], 0\n\t"
+        "s_cbranch_scc1 21f\n\t"
+        "s_ff1_i32_b64 %[ia], %[m]\n\t"
+        "s_bitset0_b64 %[m], %[ia]\n\t"
+        "v_lshl_add_u32 v90, %[ia], 4, %[base]\n\t"
+        "ds_read_b64 v[54:55], v90\n\t"
+        "ds_read_b128 v[56:59], v90 offset:%[p1]\n\t"
+        "ds_read_b128 v[60:63], v90 offset:%[p2]\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        "v_sub_f32 v91, v79, %[fpy]\n\t"
+        "v_sub_f32 v93, v78, %[fpx]\n\t"
+        "v_mul_f32 v92, v82, v91\n\t"
+        "v_mul_f32 v94, v80, v93\n\t"
+        "v_fma_f32 v92, v92, v91, v84\n\t"
+        "v_fma_f32 v94, v81, v91, v94\n\t"
+        "v_fma_f32 v88, v93, v94, v92\n\t"
+        "v_exp_f32 v89, v88\n\t"
+        "s_bitcmp1_b64 %[fa], %[ib]\n\t"
+        "s_cbranch_scc0 42f\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v77\n\t"
+        "v_mul_f32 v95, %[T], v77\n\t"
+        "v_fma_f32 %[Cr], v95, v73, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v74, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v75, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v77, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "43:\n\t"
+        "12:\n\t"
+        "s_cmp_eq_u64 %[m], 0\n\t"
+        "s_cbranch_scc1 22f\n\t"
+        "s_ff1_i32_b64 %[ib], %[m]\n\t"
+        "s_bitset0_b64 %[m], %[ib]\n\t"
+        "v_lshl_add_u32 v90, %[ib], 4, %[base]\n\t"
+        "ds_read_b64 v[66:67], v90\n\t"
+        "ds_read_b128 v[68:71], v90 offset:%[p1]\n\t"
+        "ds_read_b128 v[72:75], v90 offset:%[p2]\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        "v_sub_f32 v91, v55, %[fpy]\n\t"
+        "v_sub_f32 v93, v54, %[fpx]\n\t"
+        "v_mul_f32 v92, v58, v91\n\t"
+        "v_mul_f32 v94, v56, v93\n\t"
+        "v_fma_f32 v92, v92, v91, v60\n\t"
+        "v_fma_f32 v94, v57, v91, v94\n\t"
+        "v_fma_f32 v64, v93, v94, v92\n\t"
+        "v_exp_f32 v65, v64\n\t"
+        "s_bitcmp1_b64 %[fa], %[ic]\n\t"
+        "s_cbranch_scc0 44f\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v89\n\t"
+        "v_mul_f32 v95, %[T], v89\n\t"
+        "v_fma_f32 %[Cr], v95, v85, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v86, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v87, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v89, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "45:\n\t"
+        "s_branch 10b\n\t"
+        "20:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_sub_f32 v91, v67, %[fpy]\n\t"
+        "v_sub_f32 v93, v66, %[fpx]\n\t"
+        "v_mul_f32 v92, v70, v91\n\t"
+        "v_mul_f32 v94, v68, v93\n\t"
+        "v_fma_f32 v92, v92, v91, v72\n\t"
+        "v_fma_f32 v94, v69, v91, v94\n\t"
+        "v_fma_f32 v76, v93, v94, v92\n\t"
+        "v_exp_f32 v77, v76\n\t"
+        "s_bitcmp1_b64 %[fa], %[ia]\n\t"
+        "s_cbranch_scc0 46f\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v65\n\t"
+        "v_mul_f32 v95, %[T], v65\n\t"
+        "v_fma_f32 %[Cr], v95, v61, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v62, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v63, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v65, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "47:\n\t"
+        "s_bitcmp1_b64 %[fa], %[ib]\n\t"
+        "s_cbranch_scc0 48f\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v77\n\t"
+        "v_mul_f32 v95, %[T], v77\n\t"
+        "v_fma_f32 %[Cr], v95, v73, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v74, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v75, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v77, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "49:\n\t"
+        "s_branch 39f\n\t"
+        "21:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_sub_f32 v91, v79, %[fpy]\n\t"
+        "v_sub_f32 v93, v78, %[fpx]\n\t"
+        "v_mul_f32 v92, v82, v91\n\t"
+        "v_mul_f32 v94, v80, v93\n\t"
+        "v_fma_f32 v92, v92, v91, v84\n\t"
+        "v_fma_f32 v94, v81, v91, v94\n\t"
+        "v_fma_f32 v88, v93, v94, v92\n\t"
+        "v_exp_f32 v89, v88\n\t"
+        "s_bitcmp1_b64 %[fa], %[ib]\n\t"
+        "s_cbranch_scc0 50f\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v77\n\t"
+        "v_mul_f32 v95, %[T], v77\n\t"
+        "v_fma_f32 %[Cr], v95, v73, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v74, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v75, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v77, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "51:\n\t"
+        "s_bitcmp1_b64 %[fa], %[ic]\n\t"
+        "s_cbranch_scc0 52f\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v89\n\t"
+        "v_mul_f32 v95, %[T], v89\n\t"
+        "v_fma_f32 %[Cr], v95, v85, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v86, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v87, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v89, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "53:\n\t"
+        "s_branch 39f\n\t"
+        "22:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_sub_f32 v91, v55, %[fpy]\n\t"
+        "v_sub_f32 v93, v54, %[fpx]\n\t"
+        "v_mul_f32 v92, v58, v91\n\t"
+        "v_mul_f32 v94, v56, v93\n\t"
+        "v_fma_f32 v92, v92, v91, v60\n\t"
+        "v_fma_f32 v94, v57, v91, v94\n\t"
+        "v_fma_f32 v64, v93, v94, v92\n\t"
+        "v_exp_f32 v65, v64\n\t"
+        "s_bitcmp1_b64 %[fa], %[ic]\n\t"
+        "s_cbranch_scc0 54f\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v89\n\t"
+        "v_mul_f32 v95, %[T], v89\n\t"
+        "v_fma_f32 %[Cr], v95, v85, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v86, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v87, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v89, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "55:\n\t"
+        "s_bitcmp1_b64 %[fa], %[ia]\n\t"
+        "s_cbranch_scc0 56f\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v65\n\t"
+        "v_mul_f32 v95, %[T], v65\n\t"
+        "v_fma_f32 %[Cr], v95, v61, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v62, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v63, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v65, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "57:\n\t"
+        "s_branch 39f\n\t"
+        "30:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_sub_f32 v91, v55, %[fpy]\n\t"
+        "v_sub_f32 v93, v54, %[fpx]\n\t"
+        "v_mul_f32 v92, v58, v91\n\t"
+        "v_mul_f32 v94, v56, v93\n\t"
+        "v_fma_f32 v92, v92, v91, v60\n\t"
+        "v_fma_f32 v94, v57, v91, v94\n\t"
+        "v_fma_f32 v64, v93, v94, v92\n\t"
+        "v_exp_f32 v65, v64\n\t"
+        "s_nop 0\n\t"
+        "s_bitcmp1_b64 %[fa], %[ia]\n\t"
+        "s_cbranch_scc0 58f\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v65\n\t"
+        "v_mul_f32 v95, %[T], v65\n\t"
+        "v_fma_f32 %[Cr], v95, v61, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v62, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v63, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v65, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "59:\n\t"
+        "s_branch 39f\n\t"
+        "40:\n\t"
+        "v_cmpx_le_f32 vcc, v64, v60\n\t"
+        "v_min_f32 v65, 0x3f7d70a4, v65\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v65\n\t"
+        "v_mul_f32 v95, %[T], v65\n\t"
+        "v_fma_f32 %[Cr], v95, v61, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v62, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v63, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v65, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 41b\n\t"
+        "42:\n\t"
+        "v_cmpx_le_f32 vcc, v76, v72\n\t"
+        "v_min_f32 v77, 0x3f7d70a4, v77\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v77\n\t"
+        "v_mul_f32 v95, %[T], v77\n\t"
+        "v_fma_f32 %[Cr], v95, v73, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v74, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v75, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v77, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 43b\n\t"
+        "44:\n\t"
+        "v_cmpx_le_f32 vcc, v88, v84\n\t"
+        "v_min_f32 v89, 0x3f7d70a4, v89\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v89\n\t"
+        "v_mul_f32 v95, %[T], v89\n\t"
+        "v_fma_f32 %[Cr], v95, v85, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v86, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v87, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v89, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 45b\n\t"
+        "46:\n\t"
+        "v_cmpx_le_f32 vcc, v64, v60\n\t"
+        "v_min_f32 v65, 0x3f7d70a4, v65\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v65\n\t"
+        "v_mul_f32 v95, %[T], v65\n\t"
+        "v_fma_f32 %[Cr], v95, v61, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v62, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v63, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v65, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 47b\n\t"
+        "48:\n\t"
+        "v_cmpx_le_f32 vcc, v76, v72\n\t"
+        "v_min_f32 v77, 0x3f7d70a4, v77\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v77\n\t"
+        "v_mul_f32 v95, %[T], v77\n\t"
+        "v_fma_f32 %[Cr], v95, v73, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v74, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v75, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v77, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 49b\n\t"
+        "50:\n\t"
+        "v_cmpx_le_f32 vcc, v76, v72\n\t"
+        "v_min_f32 v77, 0x3f7d70a4, v77\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v77\n\t"
+        "v_mul_f32 v95, %[T], v77\n\t"
+        "v_fma_f32 %[Cr], v95, v73, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v74, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v75, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v77, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 51b\n\t"
+        "52:\n\t"
+        "v_cmpx_le_f32 vcc, v88, v84\n\t"
+        "v_min_f32 v89, 0x3f7d70a4, v89\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v89\n\t"
+        "v_mul_f32 v95, %[T], v89\n\t"
+        "v_fma_f32 %[Cr], v95, v85, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v86, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v87, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v89, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 53b\n\t"
+        "54:\n\t"
+        "v_cmpx_le_f32 vcc, v88, v84\n\t"
+        "v_min_f32 v89, 0x3f7d70a4, v89\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v89\n\t"
+        "v_mul_f32 v95, %[T], v89\n\t"
+        "v_fma_f32 %[Cr], v95, v85, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v86, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v87, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v89, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 55b\n\t"
+        "56:\n\t"
+        "v_cmpx_le_f32 vcc, v64, v60\n\t"
+        "v_min_f32 v65, 0x3f7d70a4, v65\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v65\n\t"
+        "v_mul_f32 v95, %[T], v65\n\t"
+        "v_fma_f32 %[Cr], v95, v61, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v62, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v63, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v65, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 57b\n\t"
+        "58:\n\t"
+        "v_cmpx_le_f32 vcc, v64, v60\n\t"
+        "v_min_f32 v65, 0x3f7d70a4, v65\n\t"
+        "v_cmpx_lt_f32 vcc, 0x3b808081, v65\n\t"
+        "v_mul_f32 v95, %[T], v65\n\t"
+        "v_fma_f32 %[Cr], v95, v61, %[Cr]\n\t"
+        "v_fma_f32 %[Cg], v95, v62, %[Cg]\n\t"
+        "v_fma_f32 %[Cb], v95, v63, %[Cb]\n\t"
+        "v_fma_f32 %[T], -%[T], v65, %[T]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 59b\n\t"
+        "39:\n\t"
+        : [T] "+v"(T), [Cr] "+v"(Cr), [Cg] "+v"(Cg), [Cb] "+v"(Cb), [m] "+s"(m), [ia] "=&s"(ia), [ib] "=&s"(ib), [ic] "=&s"(ic)
+        : [base] "v"(lds_chunk), [fpx] "v"(fpx), [fpy] "v"(fpy), [fa] "s"(fa), [p1] "i"(PLANE), [p2] "i"(2 * PLANE)
+        : "vcc", "scc", "memory", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68",
+          "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86",
+          "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+}
+
 // ---- staging -----------------------------------------------------------------------------------------------------------------
 // A tile's depth-ordered list is either a range of per-tile entries (fine binning) or, with coarse binning, the list of its 32x32
 // cell filtered by the tile's bit of the mask each entry carries in its top four bits (binning.hip): the workgroup reads the
@@ -624,9 +981,10 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
 // (a multi-GPU rank's shard) four waves per tile fill the SIMDs better and halve the per-tile critical path (G = 8 shard:
 // 0.52 vs 0.65 ms), so launch_blend picks by tile count.  Same lists, same per-quadrant classification and saturation tests,
 // same arithmetic as blend_kernel.
-template <int QPW>
-__global__ __launch_bounds__(256 / QPW, 8) void blend_walk_kernel(BlendArgs a)
+template <int QPW, bool PIPE>  // PIPE (QPW = 1 only): the pipelined walk, 96 VGPRs, for grids that 5 waves per SIMD hold
+__global__ __launch_bounds__(256 / QPW, PIPE ? 5 : 8) void blend_walk_kernel(BlendArgs a)
 {
+    static_assert(!PIPE || QPW == 1, "the pipelined walk evaluates one quadrant per wave");
     constexpr int THREADS = 256 / QPW, BATCH = THREADS, WAVES = THREADS / 64;
     __shared__ float4 srec[3][BATCH];  // planes BATCH * 16 B apart
     float4 *const s0 = srec[0], *const s1 = srec[1], *const s2 = srec[2];
@@ -688,7 +1046,9 @@ __global__ __launch_bounds__(256 / QPW, 8) void blend_walk_kernel(BlendArgs a)
             const unsigned long long fA = __ballot(fa.fast), fB = QPW == 1 ? 0ull : __ballot(fb.fast);
             evaluated += (uint32_t)__popcll(mA) + (uint32_t)__popcll(mB);
 #ifndef GSR_BLEND_NO_WALK  // analysis build: everything but the walks (staging, culling, barriers, tail)
-            if (mA | mB)
+            if constexpr (PIPE) {
+                if (mA) blend_walk1p_asm<BATCH * 16>(mA, fA, lds_rec + (unsigned)chunk * 16u, fpxA, fpy, TA, CrA, CgA, CbA);
+            } else if (mA | mB)
                 blend_walk2_asm<BATCH * 16>(mA | mB, mA, mB, fA, fB, lds_rec + (unsigned)chunk * 16u, fpxA, fpxB, fpy, TA, CrA, CgA, CbA, TB,
                                             CrB, CgB, CbB);
 #else
@@ -734,6 +1094,13 @@ __global__ __launch_bounds__(256 / QPW, 8) void blend_walk_kernel(BlendArgs a)
 
 // two quadrants per wave from this many tiles per launch on (measured: 4080 tiles better with two, 2040 with one); below, one quadrant per wave (see blend_walk_kernel)
 constexpr int BLEND_HALF_MIN_TILES = 3000;
+// the pipelined one-quadrant walk (96 VGPRs: 5 waves per SIMD = 1280 four-wave workgroups resident) up to this many tiles per launch;
+// GSR_BLEND_PIPE_TILES overrides it (experiments: 0 switches the variant off)
+static int blend_pipe_max_tiles()
+{
+    static const int v = [] { const char *e = getenv("GSR_BLEND_PIPE_TILES"); return e ? atoi(e) : 1280; }();
+    return v;
+}
 
 int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, const uint32_t *lists, void *out_image,
                  float *out_T, hipStream_t s)
@@ -768,8 +1135,9 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
                        a.cell_lists ? ws.cranges : nullptr, ws.ctiles_x);
     if (opts.accum_dtype == 1) hipLaunchKernelGGL(blend_kernel<true>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     else if (opts.blend_impl == 1) hipLaunchKernelGGL(blend_kernel<false>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
-    else if (a.rows * a.tiles_x >= BLEND_HALF_MIN_TILES) hipLaunchKernelGGL(blend_walk_kernel<2>, dim3(8u * (unsigned)slots_per_group), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL(blend_walk_kernel<1>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
+    else if (a.rows * a.tiles_x >= BLEND_HALF_MIN_TILES) hipLaunchKernelGGL((blend_walk_kernel<2, false>), dim3(8u * (unsigned)slots_per_group), dim3(128), 0, s, a);
+    else if (a.rows * a.tiles_x <= blend_pipe_max_tiles()) hipLaunchKernelGGL((blend_walk_kernel<1, true>), dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((blend_walk_kernel<1, false>), dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

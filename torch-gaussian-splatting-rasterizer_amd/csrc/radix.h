@@ -56,10 +56,10 @@ template <int THREADS, int ITEMS, bool HAS_V2>
 struct RadixTileSmem {
     static constexpr int TILE = THREADS * ITEMS, WAVES = THREADS / 64, DIGITS = THREADS;
     static_assert(THREADS == 256 || THREADS == 512, "digit d is owned by thread d");
-    static_assert(WAVES * DIGITS * 8 <= TILE * 4, "the peer masks live in the tile buffer until the reorder");
+    static constexpr int BUF_WORDS = TILE > WAVES * DIGITS * 2 ? TILE : WAVES * DIGITS * 2;  // the peer masks (8 B per wave and digit) live here too
     uint32_t wave_cnt[WAVES][DIGITS];  // per-wave digit counts, then per-wave exclusive bases
     uint32_t tile_start[DIGITS];       // start of digit d inside the reordered tile
-    uint32_t buf[TILE];                // peer masks while ranking, then one array of the tile at a time in digit order
+    uint32_t buf[BUF_WORDS];           // peer masks while ranking, then one array of the tile at a time in digit order
     uint32_t scratch[2 * WAVES];
     uint32_t n_valid;
 };

@@ -267,10 +267,10 @@ static void launch_pass(const uint32_t *kin, const uint32_t *vin, const uint32_t
 // Depth order of the gaussians (rasterize.py:424-425).  Four passes enqueued unless the caller bounds them (GsrOptions.
 // depth_sort_passes), 3 run on ordinary scenes (header); a plan that needs more than were enqueued is flagged.
 // Afterwards FrameCtrl.n_visible = V and the sorted ids / packed rects are in val[p] / rect8[p], p = sort_passes & 1.
-int launch_depth_sort(const Workspace &ws, bool packed_rect, bool compact_input, int passes, hipStream_t s)
+template <int ITEMS>
+static int depth_sort_passes(const Workspace &ws, bool packed_rect, bool compact_input, int passes, hipStream_t s)
 {
-    if (ws.n <= 0) return GSR_OK;
-    constexpr int TILE = DEPTH_SORT_THREADS * DEPTH_SORT_ITEMS;
+    constexpr int TILE = DEPTH_SORT_THREADS * ITEMS;
     const int nblk = (int)((ws.n + TILE - 1) / TILE);
     if (nblk > ws.hist_blocks) { set_error("radix sort: %d tiles exceed the histogram stride %d", nblk, ws.hist_blocks); return GSR_ERR_WORKSPACE; }
     // compact_input (multi-GPU shard): the input is FrameCtrl.n_records (key, id[, rect]) records in id order, left in
@@ -282,15 +282,23 @@ int launch_depth_sort(const Workspace &ws, bool packed_rect, bool compact_input,
         const int in = p & 1, out = in ^ 1;
         const bool first = p == 0;
         if (packed_rect)
-            launch_pass<DEPTH_SORT_THREADS, DEPTH_SORT_ITEMS, true>(ws.key[in], ws.val[in], ws.rect8[in], ws.key[out], ws.val[out], ws.rect8[out], cnt_dev, ws.n, ps,
+            launch_pass<DEPTH_SORT_THREADS, ITEMS, true>(ws.key[in], ws.val[in], ws.rect8[in], ws.key[out], ws.val[out], ws.rect8[out], cnt_dev, ws.n, ps,
                                                      first, first && !compact_input, first ? &ws.ctrl->n_visible : nullptr, ws, s);
         else
-            launch_pass<DEPTH_SORT_THREADS, DEPTH_SORT_ITEMS, false>(ws.key[in], ws.val[in], nullptr, ws.key[out], ws.val[out], nullptr, cnt_dev, ws.n, ps,
+            launch_pass<DEPTH_SORT_THREADS, ITEMS, false>(ws.key[in], ws.val[in], nullptr, ws.key[out], ws.val[out], nullptr, cnt_dev, ws.n, ps,
                                                       first, first && !compact_input, first ? &ws.ctrl->n_visible : nullptr, ws, s);
         cnt_dev = &ws.ctrl->n_visible;  // later passes only see the survivors
     }
     GSR_HIP(hipGetLastError());
     return GSR_OK;
+}
+
+int launch_depth_sort(const Workspace &ws, bool packed_rect, bool compact_input, int passes, hipStream_t s)
+{
+    if (ws.n <= 0) return GSR_OK;
+    // a shard's compact records are few (its visible gaussians): smaller tiles, more workgroups, shorter serial chains
+    return compact_input ? depth_sort_passes<DEPTH_SORT_ITEMS_SHARD>(ws, packed_rect, true, passes, s)
+                         : depth_sort_passes<DEPTH_SORT_ITEMS>(ws, packed_rect, false, passes, s);
 }
 
 // Stable sort of the (tile key, gaussian id) pairs over key bits [first_bit, key_bits), 8 bits or fewer per pass, the bits
