@@ -25,6 +25,44 @@ __device__ __forceinline__ void walk(unsigned long long m, unsigned long long ma
           "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 }
 
+// the pipelined one-quadrant walk (blend_walk1p_asm): python tools/gen_blend_walk.py pipelined > /tmp/walk1p_asm.inc
+__device__ __forceinline__ void walk1p(unsigned long long m, unsigned long long fa, unsigned lds_chunk, float fpx, float fpy, float &T, float &Cr,
+                                       float &Cg, float &Cb)
+{
+    int ia, ib, ic;
+    asm volatile(
+#include "walk1p_asm.inc"
+        : [T] "+v"(T), [Cr] "+v"(Cr), [Cg] "+v"(Cg), [Cb] "+v"(Cb), [m] "+s"(m), [ia] "=&s"(ia), [ib] "=&s"(ib), [ic] "=&s"(ic)
+        : [base] "v"(lds_chunk), [fpx] "v"(fpx), [fpy] "v"(fpy), [fa] "s"(fa), [p1] "i"(PLANE), [p2] "i"(2 * PLANE)
+        : "vcc", "scc", "memory", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68",
+          "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86",
+          "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+}
+
+__global__ __launch_bounds__(256) void kp(float *out, int chunks, unsigned long long ma, unsigned long long fa, unsigned long long *ticks)
+{
+    __shared__ float4 srec[3][128];
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 128) {
+        const int e = threadIdx.x;
+        srec[0][e] = make_float4(4.0f + 0.01f * e, 3.5f, 0.0f, 0.0f);
+        srec[1][e] = make_float4(-0.002f, 0.0005f, -0.003f, -3.0e38f);
+        srec[2][e] = make_float4(-4.0f, 0.3f, 0.5f, 0.7f);
+    }
+    __syncthreads();
+    const unsigned lds = (unsigned)(size_t)&srec[0][0];
+    const float fpx = (float)(lane & 7), fpy = (float)(lane >> 3);
+    float T = 1, Cr = 0, Cg = 0, Cb = 0;
+    const unsigned long long t0 = wall_clock64();
+    for (int c = 0; c < chunks; ++c) {
+        walk1p(ma, fa, lds, fpx, fpy, T, Cr, Cg, Cb);
+        T = T * 0.5f + 0.5f;
+    }
+    const unsigned long long t1 = wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = T + Cr + Cg + Cb;
+}
+
 __global__ __launch_bounds__(256) void k(float *out, int chunks, unsigned long long ma, unsigned long long mb, unsigned long long fa,
                                          unsigned long long fb, unsigned long long *ticks)
 {
@@ -70,6 +108,17 @@ int main()
             hipDeviceSynchronize();
             hipMemcpy(&h, ticks, 8, hipMemcpyDeviceToHost);
             printf("%d wave(s)/SIMD  %-38s %6.1f ns per record per wave\n", waves, p.name, (double)h * 10.0 / ((double)chunks * 64.0));
+        }
+    }
+    for (int waves : {1, 2, 4}) {
+        struct { const char *name; unsigned long long ma, fa; } pp[] = {{"pipelined, A only, unguarded", ALL, ALL}, {"pipelined, A only, guarded  ", ALL, 0},
+                                                                      {"pipelined, every other record", ALT, ALL}};
+        for (auto &p : pp) {
+            for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kp, dim3(256 * waves), dim3(256), 0, 0, out, chunks, p.ma, p.fa, ticks);
+            hipDeviceSynchronize();
+            hipMemcpy(&h, ticks, 8, hipMemcpyDeviceToHost);
+            const int per = p.ma == ALL ? 64 : 32;
+            printf("%d wave(s)/SIMD  %-38s %6.1f ns per record per wave\n", waves, p.name, (double)h * 10.0 / ((double)chunks * per));
         }
     }
     return 0;
