@@ -700,6 +700,30 @@ def test_fuzz_case_that_stalled_round_2_replays(G):
         assert torch.equal(got, img2 if v is cam2 else img)
 
 
+def test_f5_deep_stacks_against_the_reference_frame(G):
+    """The HIP frame of fixture f5 (see tests/test_oracle_golden.py: the reference's own frame of the deep-stack fuzz case)
+    against the REFERENCE, not the oracle: no further from it than the plain-C oracle is (111.7 dB, worst pixel 3.3e-5)."""
+    import os
+    import sys
+
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import fuzz_parity
+
+    g = load_golden("f5_deep_stack.npz")
+    c = fuzz_parity.build_case(int(g["case_seed"]), int(g["max_n"]))
+    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(c["packed"]))
+    img = R.render(G.renderer.make_camera(*c["args"])).cpu().numpy()
+    assert R.last_stats["n_visible"] <= int(g["n_drawn"])
+    d = np.abs(img.astype(np.float64) - g["image"]).max(axis=2)
+    oimg, _ = G.orc.render(c["packed"], G.orc.camera(*c["args"]))
+    do = np.abs(img.astype(np.float64) - oimg).max(axis=2)
+    print(f"\nf5 HIP vs reference: {(d > 1e-5).sum()} of {d.size} pixels off by > 1e-5, worst {d.max():.2e}, {psnr(img, g['image']):.1f} dB; "
+          f"HIP vs oracle: {(do > 1e-5).sum()} pixels, worst {do.max():.2e}")
+    assert d.max() <= 1e-4 and psnr(img, g["image"]) >= 105.0
+    assert do.max() <= 1e-4
+
+
 def test_a_fresh_workspace_needs_no_initialisation(G):
     """The C ABI asks nothing of a new workspace: every word of the control block is cleared by the frame itself, also the
     depth sort's key maximum (round 2 left that word to the caller: garbage there made a bounded first frame mis-sort).

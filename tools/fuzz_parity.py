@@ -47,7 +47,7 @@ def build_case(case_seed, max_n=60000):
     sf = int(rng.choice([1, 2, 4]))
     args = (pose.qvec, pose.tvec, sf * fx, sf * fx, sf * W, sf * H, W, H)
     degree = int(rng.choice([3, 3, 3, 0, 1, 2]))
-    return dict(rng=rng, n=n, W=W, H=H, gen=gen, shift=shift, degree=degree, pose=pose, args=args, sf=sf,
+    return dict(rng=rng, n=n, W=W, H=H, gen=gen, shift=shift, degree=degree, pose=pose, args=args, sf=sf, cols=cols,
                 packed=utils.pack_gaussians(cols))
 
 

@@ -13,7 +13,7 @@ the `plt.imshow` call at rasterize.py:471, and every helper on the hot path is
 wrapped by a recorder so its inputs/outputs are captured while the reference's
 own glue (rasterize.py:347-446) drives it.
 
-Usage:  python tools/make_golden.py [--only f1,f2,f3,f4] [--out tests/golden]
+Usage:  python tools/make_golden.py [--only f1,f2,f3,f4,f5] [--out tests/golden]
 """
 from __future__ import annotations
 
@@ -339,6 +339,26 @@ def make_f4(ref, out_dir):
     print(f"f4: drawn {len(r.draw_order)}/{n} in {dt:.1f}s (reference end-to-end), mean {img.mean():.4f}")
 
 
+def make_f5(ref, out_dir):
+    """deep stacks: the fuzz case that needed the campaign's looser per-pixel threshold (tools/fuzz_parity.py, case-seed
+    2519059510838425248: 45 918 gaussians with scales blown up e-fold on a 15x360 frame, hundreds of semi-transparent layers
+    per pixel).  The scene is rebuilt from the seed by fuzz_parity.build_case; only the reference's frame is stored."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import fuzz_parity
+
+    case_seed, max_n = 2519059510838425248, 60000
+    c = fuzz_parity.build_case(case_seed, max_n)
+    W, H, pose = c["W"], c["H"], c["pose"]
+    _, _, fx_full, fy_full, cam_w, cam_h, _, _ = c["args"]
+    cols = c["cols"]
+    r, dt = run_reference(ref, cols, [pose], pose.image_id, W, H, fx_full, fy_full, int(cam_w), int(cam_h))
+    img = r.frames[0].astype(np.float32)
+    np.savez_compressed(os.path.join(out_dir, "f5_deep_stack.npz"), case_seed=np.int64(case_seed), max_n=np.int64(max_n), n=np.int64(c["n"]),
+                        width=np.int64(W), height=np.int64(H), image=img, n_drawn=np.int64(len(r.draw_order)),
+                        reference_seconds=np.float64(dt))
+    print(f"f5: n {c['n']} {W}x{H}, drawn {len(r.draw_order)} in {dt:.1f}s, mean {img.mean():.4f}, max {img.max():.4f}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="f1,f2,f3,f4")
@@ -347,7 +367,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     ref = import_reference()
     for tag in args.only.split(","):
-        {"f1": make_f1, "f2": make_f2, "f3": make_f3, "f4": make_f4}[tag](ref, args.out)
+        {"f1": make_f1, "f2": make_f2, "f3": make_f3, "f4": make_f4, "f5": make_f5}[tag](ref, args.out)
 
 
 if __name__ == "__main__":
