@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 
 constexpr int PLANE = 2048;
 
@@ -85,13 +86,15 @@ __global__ __launch_bounds__(256) void k(float *out, int chunks, unsigned long l
     }
     const unsigned long long t1 = wall_clock64();
     if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
+    if (threadIdx.x == 0) { ticks[2 + 2 * blockIdx.x] = t0; ticks[3 + 2 * blockIdx.x] = t1; }  // every workgroup's start / end
     out[blockIdx.x * blockDim.x + threadIdx.x] = Ta + Cra + Cga + Cba + Tb + Crb + Cgb + Cbb;
 }
 
 int main()
 {
     float *out; unsigned long long *ticks, h;
-    hipMalloc(&out, 1 << 22); hipMalloc(&ticks, 8);
+    hipMalloc(&out, 1 << 22); hipMalloc(&ticks, 8 * (2 + 2 * 4096));
+    std::vector<unsigned long long> hb(2 + 2 * 4096);
     const int chunks = 2000;
     const unsigned long long ALL = ~0ull, ALT = 0x5555555555555555ull;
     struct { const char *name; unsigned long long ma, mb, fa, fb; } pat[] = {
@@ -107,7 +110,12 @@ int main()
             for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k, dim3(256 * waves), dim3(256), 0, 0, out, chunks, p.ma, p.mb, p.fa, p.fb, ticks);
             hipDeviceSynchronize();
             hipMemcpy(&h, ticks, 8, hipMemcpyDeviceToHost);
-            printf("%d wave(s)/SIMD  %-38s %6.1f ns per record per wave\n", waves, p.name, (double)h * 10.0 / ((double)chunks * 64.0));
+            // residency check: if all 256 * waves workgroups really run together, the grid's span equals one workgroup's time
+            hipMemcpy(hb.data(), ticks, 8 * (2 + 2 * 256 * waves), hipMemcpyDeviceToHost);
+            unsigned long long lo = ~0ull, hi = 0;
+            for (int b = 0; b < 256 * waves; ++b) { lo = std::min(lo, hb[2 + 2 * b]); hi = std::max(hi, hb[3 + 2 * b]); }
+            printf("%d wave(s)/SIMD  %-38s %6.1f ns per record per wave   (grid span / workgroup 0's time = %.2f)\n", waves, p.name,
+                   (double)h * 10.0 / ((double)chunks * 64.0), (double)(hi - lo) / (double)h);
         }
     }
     for (int waves : {1, 2, 4}) {
