@@ -200,8 +200,12 @@ __device__ __forceinline__ uint32_t pack_rect8(const GeoOut &g)
 }
 
 // Whole frame: one thread per gaussian.
+#ifndef GSR_PRE_THREADS
+#define GSR_PRE_THREADS 256
+#endif
+constexpr int PRE_THREADS = GSR_PRE_THREADS;  // threads per workgroup of the whole-frame kernel
 template <bool DEBUG, bool SH16>
-__global__ __launch_bounds__(256, (SH16 && !DEBUG) ? 8 : 4) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, GaussRec *__restrict__ rec,
+__global__ __launch_bounds__(PRE_THREADS, (SH16 && !DEBUG) ? 8 : 4) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, GaussRec *__restrict__ rec,
                                                          ushort4 *__restrict__ rect, uint32_t *__restrict__ rect8, uint32_t *__restrict__ depth_key,
                                                          GsrDebugOut dbg,
                                                          uint32_t *__restrict__ ctrl_words, int ctrl_reset_words, int packed_rect)
@@ -209,8 +213,8 @@ __global__ __launch_bounds__(256, (SH16 && !DEBUG) ? 8 : 4) void preprocess_kern
     // frame reset: nothing in this kernel reads FrameCtrl and every later kernel of the frame is stream-ordered behind it,
     // so workgroup 0 clears the counters here (a hipMemsetAsync costs two blit kernels and a dispatch bubble, ~20 us)
     if (blockIdx.x == 0)
-        for (int w = threadIdx.x; w < ctrl_reset_words; w += 256) ctrl_words[w] = 0u;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // the literal, not blockDim.x: that would pull in the hidden kernarg block
+        for (int w = threadIdx.x; w < ctrl_reset_words; w += PRE_THREADS) ctrl_words[w] = 0u;
+    const int64_t i = (int64_t)blockIdx.x * PRE_THREADS + threadIdx.x;  // the constant, not blockDim.x: that would pull in the hidden kernarg block
     if (i >= sc.n) return;
     // (the gaussian id is not written: pass 0 of the depth sort synthesises the identity payload, 8 B per gaussian less traffic)
     const GeoOut g = geometry_one<DEBUG>(sc, cam, compat, no_cull, row_begin, row_step, keep_ref_drawn, dbg, i);
@@ -452,7 +456,7 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
         GSR_HIP(hipMemsetAsync(ws.ctrl, 0, 4 * (size_t)ctrl_reset_words, s));
         return GSR_OK;
     }
-    const unsigned grid = (unsigned)((scene.n + 255) / 256);
+    const unsigned grid = (unsigned)((scene.n + PRE_THREADS - 1) / PRE_THREADS);
     const Cam k = make_cam(cam);
     GsrDebugOut d;
     memset(&d, 0, sizeof d);
@@ -460,7 +464,7 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
     const int row_step = opts.tile_row_step < 1 ? 1 : opts.tile_row_step, packed = rect_fits_8bit(ws) ? 1 : 0;
     const bool h16 = scene.sh_dtype == 1;
 #define GSR_LAUNCH_PRE(DBG, H16)                                                                                              \
-    hipLaunchKernelGGL((preprocess_kernel<DBG, H16>), dim3(grid), dim3(256), 0, s, scene, k, opts.reference_compat,             \
+    hipLaunchKernelGGL((preprocess_kernel<DBG, H16>), dim3(grid), dim3(PRE_THREADS), 0, s, scene, k, opts.reference_compat,     \
                        opts.no_footprint_cull, opts.tile_row_begin, row_step, opts.draw_limit > 0 ? 1 : 0, ws.rec, ws.rect,     \
                        ws.rect8[0], ws.key[0], d, reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, packed)
     // debug outputs cover every gaussian: for a shard (below) that is a pass of its own, whose other outputs are then
