@@ -203,7 +203,10 @@ __device__ __forceinline__ uint32_t pack_rect8(const GeoOut &g)
 #ifndef GSR_PRE_THREADS
 #define GSR_PRE_THREADS 256
 #endif
-constexpr int PRE_THREADS = GSR_PRE_THREADS;  // threads per workgroup of the whole-frame kernel
+// threads per workgroup of the whole-frame kernel.  128- and 64-thread builds were measured for one question only — does a smaller
+// workgroup find room beside another frame's resident blend workgroups? — and change nothing (881 -> 882 / 884 frames/s with four
+// frames in flight): tools/overlap_probe.py has the rest of that story.
+constexpr int PRE_THREADS = GSR_PRE_THREADS;
 template <bool DEBUG, bool SH16>
 __global__ __launch_bounds__(PRE_THREADS, (SH16 && !DEBUG) ? 8 : 4) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, GaussRec *__restrict__ rec,
                                                          ushort4 *__restrict__ rect, uint32_t *__restrict__ rect8, uint32_t *__restrict__ depth_key,
