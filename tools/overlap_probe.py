@@ -39,6 +39,28 @@ def copy(k):
             dst.copy_(src)
 def timed(f, reps=20):
     f(3); torch.cuda.synchronize(); t0 = time.perf_counter(); f(reps); torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
+# synthetic HBM-bound kernels (tools/probe_kernels.hip): which property lets a kernel run under the blend?
+probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libprobe.so")
+if os.path.exists(probe):
+    P = C.CDLL(probe)
+    P.probe_launch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    nvec = src.numel() // 4
+    idx = torch.randperm(nvec, device=dev, dtype=torch.int32)
+    idx = (torch.arange(nvec, device=dev, dtype=torch.int64) // 64 * 64 + (idx.long() % 64)).clamp_(max=nvec - 1).int()  # shuffled within 1-KB blocks: coalesced-ish gather
+    torch.cuda.synchronize()
+    tb0 = timed(blend)
+    for v, name in ((0, "one float4 per thread (short-lived waves)"), (5, "4 serialised float4 per thread"), (1, "32 serialised float4 per thread (long-lived waves)"),
+                    (2, "16 float4 per thread in flight (fat waves, 64+ VGPRs)"), (3, "index load -> gather (two dependent round trips)"),
+                    (4, "load -> 600 FMAs -> store (compute tail)")):
+        def run(k, v=v):
+            for _ in range(k):
+                assert P.probe_launch(v, src.data_ptr(), dst.data_ptr(), idx.data_ptr(), nvec, sb.cuda_stream) == 0
+        t1 = timed(run)
+        def both3(k, run=run):
+            for _ in range(k):
+                blend(1); run(1)
+        t2 = timed(both3)
+        print(f"probe kernel: {name:58s} alone {t1:.3f} ms, beside the blend ({tb0:.3f}) {t2:.3f} ms -> hidden {100 * (tb0 + t1 - t2) / t1:.0f} % of its time", flush=True)
 R2 = renderer.Rasterizer(scene, max_pairs=R.max_pairs)
 ws2 = R2._workspace(W, H)
 def pre(k):

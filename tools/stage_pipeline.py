@@ -16,7 +16,7 @@ cols = synthetic.mip360_like(n, 361)
 p = synthetic.ring_cameras(25)[0]
 fx = synthetic.pinhole_focal(W_)
 cam = renderer.make_camera(p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W_, 2 * H, W_, H)
-scene = renderer.GaussianScene.from_columns(cols)
+scene = renderer.GaussianScene.from_columns(cols, sh_half=os.environ.get("GSR_SH_HALF") == "1")
 opts = renderer.make_options()
 R0 = renderer.Rasterizer(scene)
 mp = R0.fit_pairs(cam, opts)
@@ -46,7 +46,22 @@ for NW in [int(x) for x in (sys.argv[1:] or ["2", "3", "4"])]:
     blended_ev = [torch.cuda.Event() for _ in range(NW)]
     torch.cuda.synchronize()
 
+    split_after_pre = os.environ.get("GSR_SPLIT") == "pre"  # stream A: preprocess only; stream B: bin/sort + blend
+
     def run(K):
+        if split_after_pre:
+            for f in range(K):
+                k = f % NW
+                ws = wss[k]
+                if f >= NW:
+                    A.wait_event(blended_ev[k])
+                check(lib.gsr_preprocess(C.byref(sc), C.byref(cam), C.byref(opts), ws.data_ptr(), ws.numel(), None, A.cuda_stream))
+                sorted_ev[k].record(A)
+                B.wait_event(sorted_ev[k])
+                check(lib.gsr_bin_sort(n, C.byref(cam), C.byref(opts), mp, ws.data_ptr(), ws.numel(), B.cuda_stream))
+                check(lib.gsr_blend(n, C.byref(cam), C.byref(opts), mp, ws.data_ptr(), ws.numel(), outs[k].data_ptr(), None, B.cuda_stream))
+                blended_ev[k].record(B)
+            return
         for f in range(K):
             k = f % NW
             ws = wss[k]
@@ -63,4 +78,4 @@ for NW in [int(x) for x in (sys.argv[1:] or ["2", "3", "4"])]:
     K = 60
     t0 = time.perf_counter(); run(K); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
     ref = R0.render(cam, opts)
-    print(f"stage pipeline, prio {os.environ.get('GSR_PRIO', '0')}, CU split {split}/8, {NW} workspaces: {dt * 1e3:.3f} ms per frame ({1 / dt:.0f} frames/s)  frames identical: {all(torch.equal(o, ref) for o in outs)}", flush=True)
+    print(f"stage pipeline, split {os.environ.get('GSR_SPLIT', 'pre+sort|blend')}, sh_half {scene.sh_half}, prio {os.environ.get('GSR_PRIO', '0')}, CU split {split}/8, {NW} workspaces: {dt * 1e3:.3f} ms per frame ({1 / dt:.0f} frames/s)  frames identical: {all(torch.equal(o, ref) for o in outs)}", flush=True)
