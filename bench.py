@@ -20,8 +20,9 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   cpu_baseline  the reference's per-gaussian torch loop, ported (oracle/torch_loop.py), timed on this host on a
                 bounded subsample of the same frame and extrapolated to the frame
 and, as extra keys that are never `value`: PSNR of the timed configuration against the CPU oracle at full size,
-per-stage times, counters, and three more legs on the same GPU — `configs2` (BASELINE configs[2]: the same scene with fp16
-SH storage and a bf16 frame store), `early_out` (blend stops a wave at T < 1e-4) and `garden` (configs[1] stand-in).
+per-stage times, counters, and more legs on the same GPU — `configs2` (BASELINE configs[2]: the same scene with fp16 SH storage
+and a bf16 frame store), `early_out` (blend stops a wave at T < 1e-4), `spatial_order` (the scene's arrays uploaded in Morton
+order), `garden` (configs[1] stand-in) and `box4k` (configs[4]: 20 M gaussians at 3840x2160, with its own roofline object).
 """
 from __future__ import annotations
 
@@ -80,7 +81,7 @@ def parse():
                     help="single: every step renders --camera; all: steps cycle over the whole camera set (configs[3])")
     ap.add_argument("--input_dir", default="", help="real data: MipNeRF-360 scene dir with sparse/0/{images,cameras}.bin")
     ap.add_argument("--trained_model_path", default="", help="real data: INRIA model dir (point_cloud/iteration_30000/point_cloud.ply)")
-    ap.add_argument("--legs", default="configs2,early_out,garden,box4k", help="extra legs at N=1 (comma list; '' = none)")
+    ap.add_argument("--legs", default="configs2,early_out,spatial_order,garden,box4k", help="extra legs at N=1 (comma list; '' = none)")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="independent frames in flight per GPU, each on its own HIP stream and workspace (1 = one stream; the "
                          "single-stream figure is reported beside the headline either way)")
@@ -442,6 +443,25 @@ def main():
                                   "frame_storage": "bf16 (fp32 accumulation)", "fetched_entries": s["fetched_entries"],
                                   "note": "not the headline: BASELINE configs[2] storage options on the same scene and camera"}
             del Rh, scene_h, h_out
+
+        # (2b) the same scene uploaded in Morton order of the means (GaussianScene spatial_order: a loader option, the frame is the
+        # same up to the mutual order of gaussians at exactly equal depth, which the reference leaves undefined): waves are culled
+        # whole, the SH rows of the visible gaussians are contiguous, the blend's record gathers hit L2 more often
+        if "spatial_order" in legs and not args.sh_half:
+            scene_m = renderer.GaussianScene.from_packed(packed, device=dev, spatial_order=True)
+            Rm = renderer.Rasterizer(scene_m, max_pairs=R.max_pairs)
+            m_opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl)
+            m_out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+            Rm.render(cam, m_opts, out=m_out)  # learns the depth-sort bound
+            el = timed_frames(Rm, cams, m_opts, m_out, steps_leg, warm_leg, dev, S)
+            mprof = stage_profile(Rm, scene_m, cam, Rm.bounded(m_opts), (H, W, 3), ((W + 15) // 16) * ((H + 15) // 16), 10, False, {}, dev)
+            Rm.enqueue(cam, m_opts, out=m_out)
+            leg_imgs["spatial_order"] = m_out.cpu().numpy()
+            result["spatial_order"] = {"frames_per_s": steps_leg / el, "ms_per_step": 1e3 * el / steps_leg, "stage_ms": mprof["stage_ms"],
+                                       "stats": mprof["stats"],
+                                       "note": "not the headline: the same scene, camera and arithmetic with the gaussians' arrays uploaded in Morton "
+                                               "order of their means instead of file order (renderer.GaussianScene spatial_order=True)"}
+            del Rm, scene_m, m_out
 
         oracle_img = None
         pre = order = None

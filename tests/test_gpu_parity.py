@@ -724,6 +724,36 @@ def test_f5_deep_stacks_against_the_reference_frame(G):
     assert do.max() <= 1e-4
 
 
+def test_spatial_order_renders_the_same_frame(G):
+    """GaussianScene(spatial_order=True) uploads the arrays in Morton order of the means (renderer.morton_order: a permutation).
+    The reference's result does not depend on storage order — its depth sort orders the draw — except for gaussians at exactly
+    equal depth, so: same counters; the frame bit-identical when no two visible gaussians share a depth, and within the usual
+    tolerance of the oracle either way."""
+    cols, cam, ocam = _medium(G, n=150_000)
+    packed = G.utils.pack_gaussians(cols)
+    plain = G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(packed))
+    scene = G.renderer.GaussianScene.from_packed(packed, spatial_order=True)
+    assert sorted(scene.order.tolist()) == list(range(150_000)) and not np.array_equal(scene.order, np.arange(150_000))
+    assert np.array_equal(scene.t["means"].cpu().numpy(), packed["means"][scene.order])
+    R = G.renderer.Rasterizer(scene)
+    a, b = plain.render(cam), R.render(cam)
+    for k in ("n_visible", "n_pairs_bbox", "n_pairs"):
+        assert plain.last_stats[k] == R.last_stats[k], k
+    z = plain.preprocess_debug(cam)["cam_means"][:, 2].cpu().numpy()
+    vis = z[z >= 0.2]
+    ties = len(vis) - len(np.unique(vis))
+    if ties == 0:
+        assert torch.equal(a, b)
+    assert float((a - b).abs().max()) < 1e-4 and psnr(b.cpu().numpy(), a.cpu().numpy()) >= 110.0, ties
+    oimg, _ = G.orc.render(packed, ocam)
+    assert_frames_close(b.cpu().numpy(), oimg)
+    # per-gaussian outputs are in scene order: order maps them back to file order
+    dbg = R.preprocess_debug(cam)["cam_means"].cpu().numpy()
+    back = np.empty_like(dbg)
+    back[scene.order] = dbg
+    assert np.array_equal(back[:, 2], z)
+
+
 def test_a_fresh_workspace_needs_no_initialisation(G):
     """The C ABI asks nothing of a new workspace: every word of the control block is cleared by the frame itself, also the
     depth sort's key maximum (round 2 left that word to the caller: garbage there made a bounded first frame mis-sort).

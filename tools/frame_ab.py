@@ -29,8 +29,10 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     cols, cam_list, n, W, H, _ = bench.build_workload(a.workload, a, a.gaussians)
-    scene = renderer.GaussianScene.from_packed(utils.pack_gaussians(cols), device=dev)
+    packed = utils.pack_gaussians(cols)
     del cols
+    scene = renderer.GaussianScene.from_packed(packed, device=dev, spatial_order=os.environ.get("GSR_MORTON") == "1")  # A/B of the loader option
+    del packed
     cam = renderer.make_camera(*cam_list[0])
     variants = []
     for v in a.variants:

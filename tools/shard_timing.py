@@ -19,7 +19,7 @@ cols = synthetic.mip360_like(n, seed)
 p = synthetic.ring_cameras(25)[0]
 fx = synthetic.pinhole_focal(W)
 cam = renderer.make_camera(p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H)
-scene = renderer.GaussianScene.from_columns(cols)
+scene = renderer.GaussianScene.from_columns(cols, spatial_order=os.environ.get("GSR_MORTON") == "1")  # the loader's Morton-order option
 
 
 def timed(fif, opts, outs, frames=24):
