@@ -129,3 +129,19 @@ def test_look_at_pose_geometry():
         c = rot(p.qvec) @ np.zeros(3) + p.tvec                     # the origin, seen from the ring camera
         np.testing.assert_allclose(c[:2], 0, atol=1e-9)
         assert abs(c[2] - np.hypot(4.0, 1.0)) < 1e-9
+
+
+def test_morton_order_is_a_locality_preserving_permutation():
+    """renderer.morton_order (GaussianScene spatial_order=True): a permutation of the gaussians along a Z-order curve of their
+    means, balanced by rank quantisation whatever the scene's extent — consecutive gaussians are spatial neighbours."""
+    from gsr_amd import renderer, synthetic
+
+    cols = synthetic.mip360_like(20000, 9)
+    m = np.stack([cols[k] for k in "xyz"], 1)
+    p = renderer.morton_order(m)
+    assert sorted(p.tolist()) == list(range(len(m))) and len(renderer.morton_order(m[:0])) == 0
+    # neighbours in curve order are much closer in rank space (every axis rank-scaled to [0, 1]) than neighbours in file order
+    r = np.stack([np.argsort(np.argsort(m[:, a])) for a in range(3)], 1) / len(m)
+    step = lambda q: float(np.median(np.linalg.norm(np.diff(q, axis=0), axis=1)))
+    assert step(r[p]) < 0.2 * step(r)
+    assert np.array_equal(renderer.morton_order(m), p)          # deterministic
