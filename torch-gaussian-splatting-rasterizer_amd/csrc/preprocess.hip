@@ -11,6 +11,7 @@
 // SH 192) + 52..64 written per visible gaussian.  Culled / off-screen gaussians
 // leave before the SH read.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include "gsr_internal.h"
@@ -194,6 +195,36 @@ __device__ __forceinline__ void colour_one(const GsrScene &sc, const Cam &cam, i
     sh_eval(p, sh, cam.cc, sc.sh_degree, rgb);
 }
 
+// The SH rows of a whole wave (64 consecutive gaussians: 12 KB, contiguous) through LDS, for waves most of whose gaussians are
+// visible — what a scene uploaded in spatial order (renderer.morton_order) makes of nearly every wave that is not culled whole.
+// Per-lane loads of a 192-B row at 192-B stride touch 64 different lines per instruction; here every instruction is one fully
+// coalesced 1-KB load, written straight to LDS (global_load_lds_dwordx4: no staging registers), and a lane then reads its own row
+// with 12 ds_read_b128.  Two rounds of 32 rows keep it to 6 KB of LDS per wave.  Same values into the same registers: nothing
+// downstream can tell.  (A timing probe in FILE order, where 55 % of a wave's lanes are visible, measured this pattern SLOWER than
+// per-lane loads — it fetches every line of the array instead of 74 % of them and the kernel is bound by HBM: hence the density
+// test at the call site.)
+__device__ __forceinline__ void load_sh48_wave(const float *sh, int64_t i0, int lane, float4 *lds /* this wave's 384 float4 */, float out[48])
+{
+    const float4 *base = reinterpret_cast<const float4 *>(sh + 48 * i0) + lane;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)  // LDS destination: wave-uniform base + lane * 16
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (6 * h + k) * 64),
+                                             (__attribute__((address_space(3))) void *)(lds + k * 64), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have landed (an LDS-DMA counts on vmcnt)
+        if ((lane >> 5) == h) {
+            const float4 *row = lds + (lane & 31) * 12;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const float4 v = row[j];
+                out[4 * j] = v.x; out[4 * j + 1] = v.y; out[4 * j + 2] = v.z; out[4 * j + 3] = v.w;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read before the next round's DMA overwrites the buffer
+    }
+}
+
 __device__ __forceinline__ uint32_t pack_rect8(const GeoOut &g)
 {
     return (uint32_t)(g.tx0 & 255) | ((uint32_t)(g.ty0 & 255) << 8) | ((uint32_t)((g.tx1 - 1) & 255) << 16) | ((uint32_t)((g.ty1 - 1) & 255) << 24);
@@ -211,8 +242,10 @@ template <bool DEBUG, bool SH16>
 __global__ __launch_bounds__(PRE_THREADS, (SH16 && !DEBUG) ? 8 : 4) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, GaussRec *__restrict__ rec,
                                                          ushort4 *__restrict__ rect, uint32_t *__restrict__ rect8, uint32_t *__restrict__ depth_key,
                                                          GsrDebugOut dbg,
-                                                         uint32_t *__restrict__ ctrl_words, int ctrl_reset_words, int packed_rect)
+                                                         uint32_t *__restrict__ ctrl_words, int ctrl_reset_words, int packed_rect, int sh_dense_min)
 {
+    constexpr bool WAVE_SH = !DEBUG && !SH16;  // fp32 rows of a dense wave go through LDS (load_sh48_wave)
+    __shared__ float4 s_sh[WAVE_SH ? (PRE_THREADS / 64) * 384 : 1];
     // frame reset: nothing in this kernel reads FrameCtrl and every later kernel of the frame is stream-ordered behind it,
     // so workgroup 0 clears the counters here (a hipMemsetAsync costs two blit kernels and a dispatch bubble, ~20 us)
     if (blockIdx.x == 0)
@@ -222,7 +255,19 @@ __global__ __launch_bounds__(PRE_THREADS, (SH16 && !DEBUG) ? 8 : 4) void preproc
     // (the gaussian id is not written: pass 0 of the depth sort synthesises the identity payload, 8 B per gaussian less traffic)
     const GeoOut g = geometry_one<DEBUG>(sc, cam, compat, no_cull, row_begin, row_step, keep_ref_drawn, dbg, i);
     float rgb[3] = {0.f, 0.f, 0.f};
-    if (g.visible || (DEBUG && dbg.rgb)) {
+    bool coloured = false;
+    if constexpr (WAVE_SH) {
+        const int lane = threadIdx.x & 63;
+        const int64_t i0 = i - lane;
+        // wave-uniform: a full wave (the last one of the grid may not be) with at least sh_dense_min visible gaussians
+        if (i0 + 64 <= sc.n && (int)__popcll(__ballot(g.visible)) >= sh_dense_min) {
+            float sh[48];
+            load_sh48_wave(reinterpret_cast<const float *>(sc.sh), i0, lane, s_sh + (threadIdx.x >> 6) * 384, sh);
+            if (g.visible) sh_eval(g.p, sh, cam.cc, sc.sh_degree, rgb);
+            coloured = true;
+        }
+    }
+    if (!coloured && (g.visible || (DEBUG && dbg.rgb))) {
         colour_one<SH16>(sc, cam, i, g.p, rgb);
         if (DEBUG && dbg.rgb) { dbg.rgb[3 * i] = rgb[0]; dbg.rgb[3 * i + 1] = rgb[1]; dbg.rgb[3 * i + 2] = rgb[2]; }
     }
@@ -466,10 +511,13 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
     if (dbg) d = *dbg;
     const int row_step = opts.tile_row_step < 1 ? 1 : opts.tile_row_step, packed = rect_fits_8bit(ws) ? 1 : 0;
     const bool h16 = scene.sh_dtype == 1;
+    // from how many visible gaussians per wave on the wave's SH rows are fetched whole through LDS (load_sh48_wave); GSR_SH_DENSE
+    // overrides it for experiments (65 = never)
+    static const int sh_dense_min = [] { const char *e = getenv("GSR_SH_DENSE"); return e ? atoi(e) : 48; }();
 #define GSR_LAUNCH_PRE(DBG, H16)                                                                                              \
     hipLaunchKernelGGL((preprocess_kernel<DBG, H16>), dim3(grid), dim3(PRE_THREADS), 0, s, scene, k, opts.reference_compat,     \
                        opts.no_footprint_cull, opts.tile_row_begin, row_step, opts.draw_limit > 0 ? 1 : 0, ws.rec, ws.rect,     \
-                       ws.rect8[0], ws.key[0], d, reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, packed)
+                       ws.rect8[0], ws.key[0], d, reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, packed, sh_dense_min)
     // debug outputs cover every gaussian: for a shard (below) that is a pass of its own, whose other outputs are then
     // overwritten
     if (dbg) { if (h16) GSR_LAUNCH_PRE(true, true); else GSR_LAUNCH_PRE(true, false); }
