@@ -6,7 +6,8 @@
 A step = one complete 1920x1080 frame of the synthetic stand-in for MipNeRF-360 'bicycle' — the scene BASELINE.json's
 metric is quoted on (mip360_like(6_131_954, seed 361), ring camera 0) — in the reference's own
 arithmetic: fp32 coefficients, fp32 frame, reference_compat, every gaussian blended (no approximate early termination):
-preprocess -> depth sort -> tile binning -> blend, scene resident in HBM before the timed region.  With N > 1 the SAME
+preprocess -> depth sort -> tile binning -> blend, scene resident in HBM before the timed region — uploaded by the loader along a
+Morton curve of the gaussians' means (--scene-order; the `file_order` leg is the same frame from file-order arrays).  With N > 1 the SAME
 frame is sharded by interleaved tile rows over the N GPUs and gathered to rank 0 over RCCL (strong scaling: total work
 per frame fixed).  `value` is throughput: --frames-in-flight independent frames (default 4) are in flight per GPU, each on
 its own HIP stream with its own workspace (renderer.FramesInFlight), every frame complete and bit-identical to
@@ -21,8 +22,9 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                 bounded subsample of the same frame and extrapolated to the frame
 and, as extra keys that are never `value`: PSNR of the timed configuration against the CPU oracle at full size,
 per-stage times, counters, and more legs on the same GPU — `configs2` (BASELINE configs[2]: the same scene with fp16 SH storage
-and a bf16 frame store), `early_out` (blend stops a wave at T < 1e-4), `spatial_order` (the scene's arrays uploaded in Morton
-order), `garden` (configs[1] stand-in) and `box4k` (configs[4]: 20 M gaussians at 3840x2160, with its own roofline object).
+and a bf16 frame store), `early_out` (blend stops a wave at T < 1e-4), `file_order` (the scene's arrays uploaded in file order
+instead of along a Morton curve: what rounds 1-2 measured), `garden` (configs[1] stand-in) and `box4k` (configs[4]: 20 M
+gaussians at 3840x2160, with its own roofline object).
 """
 from __future__ import annotations
 
@@ -81,7 +83,11 @@ def parse():
                     help="single: every step renders --camera; all: steps cycle over the whole camera set (configs[3])")
     ap.add_argument("--input_dir", default="", help="real data: MipNeRF-360 scene dir with sparse/0/{images,cameras}.bin")
     ap.add_argument("--trained_model_path", default="", help="real data: INRIA model dir (point_cloud/iteration_30000/point_cloud.ply)")
-    ap.add_argument("--legs", default="configs2,early_out,spatial_order,garden,box4k", help="extra legs at N=1 (comma list; '' = none)")
+    ap.add_argument("--legs", default="configs2,early_out,file_order,garden,box4k", help="extra legs at N=1 (comma list; '' = none)")
+    ap.add_argument("--scene-order", default="morton", choices=["morton", "file"],
+                    help="how the loader lays the gaussians' arrays out in HBM: along a Morton curve of their means (renderer.GaussianScene "
+                         "spatial_order=True: the same frame up to the mutual order of gaussians at exactly equal depth, which the reference "
+                         "leaves undefined) or in file order; the `file_order` leg reports the other one")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="independent frames in flight per GPU, each on its own HIP stream and workspace (1 = one stream; the "
                          "single-stream figure is reported beside the headline either way)")
@@ -268,7 +274,8 @@ def main():
     cam_args = cam_list[0]
     packed = utils.pack_gaussians(cols)
     del cols
-    scene = renderer.GaussianScene.from_packed(packed, device=dev, sh_half=args.sh_half)
+    spatial = args.scene_order == "morton"
+    scene = renderer.GaussianScene.from_packed(packed, device=dev, sh_half=args.sh_half, spatial_order=spatial)
     cams = [renderer.make_camera(*c) for c in cam_list]
     cam = cams[0]
     ncam = len(cams)
@@ -386,6 +393,7 @@ def main():
             "config": {"workload": f"{'real' if real else args.workload}: {desc}", "gaussians": n, "width": W, "height": H,
                        "camera": args.camera if ncam == 1 else f"cycling over {ncam} cameras",
                        "sharding": f"tile rows interleaved over {world} GPU(s), RCCL gather to rank 0" if world > 1 else "none",
+                       "scene_order": "morton curve of the means (loader option spatial_order; same frame up to exact depth ties)" if spatial else "file",
                        "reference_compat": True, "early_out_T": args.early_out_T, "depth_sort_passes": R.sort_passes, "sh_storage": "f16" if args.sh_half else "f32",
                        "frame_storage": "bf16 (fp32 accumulation)" if args.bf16_output else "f32",
                        "blend_impl": {0: "valu", 1: "valu, plain-C walk"}.get(args.blend_impl, str(args.blend_impl))},
@@ -431,7 +439,7 @@ def main():
         # (2) BASELINE configs[2]: fp16 SH storage + bf16 frame store (accumulation stays fp32: bf16 accumulators measure 41 dB,
         # below the 50 dB bar).  PSNR below is against the fp32 oracle of the fp32 coefficients.
         if "configs2" in legs and not args.sh_half:
-            scene_h = renderer.GaussianScene.from_packed(packed, device=dev, sh_half=True)
+            scene_h = renderer.GaussianScene.from_packed(packed, device=dev, sh_half=True, spatial_order=spatial)
             Rh = renderer.Rasterizer(scene_h, max_pairs=R.max_pairs)
             h_opts = renderer.make_options(output_bf16=True)
             h_out = torch.empty((H, W, 3), dtype=torch.bfloat16, device=dev)
@@ -444,11 +452,12 @@ def main():
                                   "note": "not the headline: BASELINE configs[2] storage options on the same scene and camera"}
             del Rh, scene_h, h_out
 
-        # (2b) the same scene uploaded in Morton order of the means (GaussianScene spatial_order: a loader option, the frame is the
-        # same up to the mutual order of gaussians at exactly equal depth, which the reference leaves undefined): waves are culled
-        # whole, the SH rows of the visible gaussians are contiguous, the blend's record gathers hit L2 more often
-        if "spatial_order" in legs and not args.sh_half:
-            scene_m = renderer.GaussianScene.from_packed(packed, device=dev, spatial_order=True)
+        # (2b) the same scene uploaded in the OTHER order (headline: along a Morton curve of the means — waves are culled whole, the SH
+        # rows of the visible gaussians are contiguous, the blend's record gathers hit L2 more often; this leg: file order, as the
+        # reference reads the .ply and as rounds 1-2 measured).  The frame is the same up to the mutual order of gaussians at exactly
+        # equal depth, which the reference leaves undefined.
+        if "file_order" in legs and not args.sh_half:
+            scene_m = renderer.GaussianScene.from_packed(packed, device=dev, spatial_order=not spatial)
             Rm = renderer.Rasterizer(scene_m, max_pairs=R.max_pairs)
             m_opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl)
             m_out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
@@ -456,11 +465,11 @@ def main():
             el = timed_frames(Rm, cams, m_opts, m_out, steps_leg, warm_leg, dev, S)
             mprof = stage_profile(Rm, scene_m, cam, Rm.bounded(m_opts), (H, W, 3), ((W + 15) // 16) * ((H + 15) // 16), 10, False, {}, dev)
             Rm.enqueue(cam, m_opts, out=m_out)
-            leg_imgs["spatial_order"] = m_out.cpu().numpy()
-            result["spatial_order"] = {"frames_per_s": steps_leg / el, "ms_per_step": 1e3 * el / steps_leg, "stage_ms": mprof["stage_ms"],
-                                       "stats": mprof["stats"],
-                                       "note": "not the headline: the same scene, camera and arithmetic with the gaussians' arrays uploaded in Morton "
-                                               "order of their means instead of file order (renderer.GaussianScene spatial_order=True)"}
+            leg_imgs["file_order"] = m_out.cpu().numpy()
+            result["file_order"] = {"scene_order": "file" if spatial else "morton", "frames_per_s": steps_leg / el, "ms_per_step": 1e3 * el / steps_leg,
+                                    "stage_ms": mprof["stage_ms"], "stats": mprof["stats"],
+                                    "note": "not the headline: the same scene, camera and arithmetic with the gaussians' arrays uploaded in the other "
+                                            "order (file order when the headline is Morton order, the loader's spatial_order option, and vice versa)"}
             del Rm, scene_m, m_out
 
         oracle_img = None
@@ -507,7 +516,7 @@ def main():
             del R, scene, packed
             torch.cuda.empty_cache()
             gcols, gcam_list, gn, _, _, gdesc = build_workload("garden", args)
-            gscene = renderer.GaussianScene.from_columns(gcols, device=dev)
+            gscene = renderer.GaussianScene.from_columns(gcols, device=dev, spatial_order=spatial)
             del gcols
             gcams = [renderer.make_camera(*c) for c in gcam_list]
             Rg = renderer.Rasterizer(gscene)
@@ -526,7 +535,7 @@ def main():
             R = scene = packed = fif = frames = leg_out = strip_view = frame = Rg = gscene = None  # the other scenes leave HBM
             torch.cuda.empty_cache()
             bcols, bcam_list, bn, bW, bH, bdesc = build_workload("box4k", args)
-            bscene = renderer.GaussianScene.from_columns(bcols, device=dev)
+            bscene = renderer.GaussianScene.from_columns(bcols, device=dev, spatial_order=spatial)
             del bcols
             bcam = renderer.make_camera(*bcam_list[0])
             Rb = renderer.Rasterizer(bscene)
