@@ -163,8 +163,8 @@ class Rasterizer:
             self._ws = None  # free the old one first
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.scene.device)
             assert self._ws.data_ptr() % 256 == 0
-            # the counter block at the head starts defined: stats() before any frame reads zeros, and the depth sort's
-            # running key maximum (the one word libgsr carries from frame to frame) starts at 0 instead of garbage
+            # libgsr needs no initialisation (every frame clears its control block); the head is zeroed only so that a
+            # gsr_read_stats BEFORE any frame has run on this workspace reads zeros rather than whatever the allocator left
             self._ws[: min(4096, nbytes)].zero_()
             self._ws_key = key
             self._chained = self._last_empty = False
@@ -277,6 +277,8 @@ class Rasterizer:
         if opts.output_layout != 0 or opts.tile_row_step > 1:
             raise ValueError("render_batch renders whole [H,W,3] frames")
         cams = list(cams)
+        if not cams:
+            raise ValueError("render_batch needs at least one view")
         arr = (GsrCamera * len(cams))(*cams)
         W, H = cams[0].width, cams[0].height
         dtype = torch.bfloat16 if opts.output_dtype == 1 else torch.float32
@@ -284,8 +286,6 @@ class Rasterizer:
             out = torch.empty((len(cams), H, W, 3), dtype=dtype, device=self.scene.device)
         elif tuple(out.shape) != (len(cams), H, W, 3) or out.dtype != dtype or not out.is_contiguous() or not out.is_cuda:
             raise ValueError(f"out must be a contiguous {dtype} CUDA tensor of shape {(len(cams), H, W, 3)}")
-        if not cams:
-            return out
         sc = self.scene.c_struct()
         unbounded = False
         for _ in range(MAX_RETRIES + 1):
@@ -390,6 +390,8 @@ class FramesInFlight:
         if opts.output_layout != 0 or opts.tile_row_step > 1:
             raise ValueError("render_batch renders whole [H,W,3] frames")
         cams = list(cams)
+        if not cams:
+            raise ValueError("render_batch needs at least one view")
         arr = (GsrCamera * len(cams))(*cams)
         W, H = cams[0].width, cams[0].height
         dev = self.scene.device
@@ -398,8 +400,6 @@ class FramesInFlight:
             out = torch.empty((len(cams), H, W, 3), dtype=dtype, device=dev)
         elif tuple(out.shape) != (len(cams), H, W, 3) or out.dtype != dtype or not out.is_contiguous() or not out.is_cuda:
             raise ValueError(f"out must be a contiguous {dtype} CUDA tensor of shape {(len(cams), H, W, 3)}")
-        if not cams:
-            return out
         sc = self.scene.c_struct()
         n = len(self.rasterizers)
         cur = torch.cuda.current_stream(dev)
