@@ -158,6 +158,12 @@ def main():
                 screen, _, _ = orc.composite(order, pre, W, H, limit=k)
                 if k > 0:
                     close(R.render(cam, mk(draw_limit=k)).cpu().numpy(), screen.transpose(1, 0, 2))
+            # the loader's Morton order: the same frame, bit for bit unless two visible gaussians share a depth exactly
+            Rm = renderer.Rasterizer(renderer.GaussianScene.from_packed(packed, sh_degree=degree, spatial_order=True))
+            mimg = Rm.render(cam)
+            close(mimg.cpu().numpy(), oimg)
+            R.render(cam)
+            assert Rm.last_stats["n_visible"] == R.last_stats["n_visible"] and Rm.last_stats["n_pairs"] == R.last_stats["n_pairs"], "spatial order changes the lists"
             half = renderer.Rasterizer(renderer.GaussianScene.from_packed(packed, sh_degree=degree, sh_half=True))
             h = half.render(cam)
             assert torch.equal(half.render(cam, mk(no_footprint_cull=True)), h), "fp16 SH: culling changes bits"
