@@ -12,11 +12,13 @@
  *   - all device work is enqueued on the caller's hipStream_t (passed as void*); nothing synchronises
  *     except gsr_read_stats.
  *   - fp32 throughout (the reference's arithmetic type); device pointers unless marked [host].
- *   - three environment switches exist, for A/B timing and tests only (same frames either way): GSR_FINE_BINNING=1 (read per
+ *   - four environment switches exist, for A/B timing and tests only (same frames either way): GSR_FINE_BINNING=1 (read per
  *     call) generates the (gaussian, tile) pairs per 16x16 tile directly instead of per 32x32 cell (csrc/binning.hip);
  *     GSR_SHARD_PREPROCESS=0/1 (read once per process) forces the whole-frame / the three-phase preprocess for tile-row
  *     shards instead of choosing by tile_row_step (csrc/preprocess.hip); GSR_BLEND_PIPE_TILES=n (read once per process)
- *     moves the tile count up to which the blend uses its pipelined one-quadrant walk (default 1280; 0 = never; csrc/blend.hip).
+ *     moves the tile count up to which the blend uses its pipelined one-quadrant walk (default 1280; 0 = never; csrc/blend.hip);
+ *     GSR_SH_DENSE=n (read once per process) the number of visible gaussians from which a wave of the preprocess fetches its 64 SH
+ *     rows whole through LDS (default 48; 65 = never; csrc/preprocess.hip).
  */
 #ifndef GSR_H
 #define GSR_H
