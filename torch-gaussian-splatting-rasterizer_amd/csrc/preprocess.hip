@@ -238,9 +238,10 @@ __device__ __forceinline__ uint32_t pack_rect8(const GeoOut &g)
 // workgroup find room beside another frame's resident blend workgroups? — and change nothing (881 -> 882 / 884 frames/s with four
 // frames in flight): tools/overlap_probe.py has the rest of that story.
 constexpr int PRE_THREADS = GSR_PRE_THREADS;
-// Register budget: fp32 SH 94 VGPRs (5 waves per SIMD); fp16 storage 76 at 6 waves — asked for 8 it fits 64 with a few bytes of
-// spill and is 3-5 % slower (0.158 vs 0.150 ms on the Morton-ordered bench scene).  The wave-wide row loads give fp16 nothing
-// (0.150 ms with and without: six per-lane loads at a 96-B stride are already cheap), so only fp32 has them.
+// Register budget: fp32 SH 94 VGPRs (5 waves per SIMD); fp16 storage 67 (7 waves) — asked for 8 waves it fits 64 with a few bytes
+// of spill and is 3-5 % slower (0.158 vs 0.150 ms on the Morton-ordered bench scene, the latter measured at 76 VGPRs / 6 waves).
+// The wave-wide row loads give fp16 nothing (0.150 ms with and without: six per-lane loads at a 96-B stride are already cheap),
+// so only fp32 has them.
 template <bool DEBUG, bool SH16>
 __global__ __launch_bounds__(PRE_THREADS, (SH16 && !DEBUG) ? 6 : 4) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, GaussRec *__restrict__ rec,
                                                          ushort4 *__restrict__ rect, uint32_t *__restrict__ rect8, uint32_t *__restrict__ depth_key,
