@@ -9,7 +9,7 @@ arithmetic: fp32 coefficients, fp32 frame, reference_compat, every gaussian blen
 preprocess -> depth sort -> tile binning -> blend, scene resident in HBM before the timed region — uploaded by the loader along a
 Morton curve of the gaussians' means (--scene-order; the `file_order` leg is the same frame from file-order arrays).  With N > 1 the SAME
 frame is sharded by interleaved tile rows over the N GPUs and gathered to rank 0 over RCCL (strong scaling: total work
-per frame fixed).  `value` is throughput: --frames-in-flight independent frames (default 4) are in flight per GPU, each on
+per frame fixed).  `value` is throughput: --frames-in-flight independent frames (default 6; 4 with N > 1) are in flight per GPU, each on
 its own HIP stream with its own workspace (renderer.FramesInFlight), every frame complete and bit-identical to
 single-stream rendering; `single_stream` carries the same loop with one frame in flight (the per-frame latency), and the
 per-stage times / roofline are measured on one stream.
@@ -88,7 +88,7 @@ def parse():
                     help="how the loader lays the gaussians' arrays out in HBM: along a Morton curve of their means (renderer.GaussianScene "
                          "spatial_order=True: the same frame up to the mutual order of gaussians at exactly equal depth, which the reference "
                          "leaves undefined) or in file order; the `file_order` leg reports the other one")
-    ap.add_argument("--frames-in-flight", type=int, default=4,
+    ap.add_argument("--frames-in-flight", type=int, default=None,
                     help="independent frames in flight per GPU, each on its own HIP stream and workspace (1 = one stream; the "
                          "single-stream figure is reported beside the headline either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -281,7 +281,9 @@ def main():
     ncam = len(cams)
     plan = gdist.TileRowPlan(H, W, world)
     out_dtype = torch.bfloat16 if args.bf16_output else torch.float32
-    S = max(1, args.frames_in_flight)
+    # default: 6 on one GPU (sweep in DESIGN.md §7: 3, 5, 6 and 8 agree within noise, 4 is ~3 % below them), 4 with N > 1 (the
+    # schedule the multi-GPU runs were validated with: one outstanding RCCL gather per slot)
+    S = max(1, args.frames_in_flight if args.frames_in_flight is not None else (6 if world == 1 else 4))
     fif = renderer.FramesInFlight(scene, slots=S)
     R = fif.rasterizers[0]
     state = {"i": 0}
