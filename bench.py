@@ -9,7 +9,7 @@ arithmetic: fp32 coefficients, fp32 frame, reference_compat, every gaussian blen
 preprocess -> depth sort -> tile binning -> blend, scene resident in HBM before the timed region — uploaded by the loader along a
 Morton curve of the gaussians' means (--scene-order; the `file_order` leg is the same frame from file-order arrays).  With N > 1 the SAME
 frame is sharded by interleaved tile rows over the N GPUs and gathered to rank 0 over RCCL (strong scaling: total work
-per frame fixed).  `value` is throughput: --frames-in-flight independent frames (default 6; 4 with N > 1) are in flight per GPU, each on
+per frame fixed).  `value` is throughput: --frames-in-flight independent frames (default 6) are in flight per GPU, each on
 its own HIP stream with its own workspace (renderer.FramesInFlight), every frame complete and bit-identical to
 single-stream rendering; `single_stream` carries the same loop with one frame in flight (the per-frame latency), and the
 per-stage times / roofline are measured on one stream.
@@ -281,9 +281,9 @@ def main():
     ncam = len(cams)
     plan = gdist.TileRowPlan(H, W, world)
     out_dtype = torch.bfloat16 if args.bf16_output else torch.float32
-    # default: 6 on one GPU (sweep in DESIGN.md §7: 3, 5, 6 and 8 agree within noise, 4 is ~3 % below them), 4 with N > 1 (the
-    # schedule the multi-GPU runs were validated with: one outstanding RCCL gather per slot)
-    S = max(1, args.frames_in_flight if args.frames_in_flight is not None else (6 if world == 1 else 4))
+    # default 6 (sweeps in DESIGN.md §7: whole frames 3, 5, 6 and 8 agree within noise and 4 is ~3 % below them; tile-row shards
+    # G = 2 / 4 / 8: 6 is 7-12 % ahead of 4 and 3-6 % ahead of 8)
+    S = max(1, args.frames_in_flight if args.frames_in_flight is not None else 6)
     fif = renderer.FramesInFlight(scene, slots=S)
     R = fif.rasterizers[0]
     state = {"i": 0}

@@ -52,8 +52,8 @@ def _worker(rank, world, port, H, W, q):
 
 
 def _pipeline_worker(rank, world, port, H, W, q):
-    """dist.ShardedFrames (bench.py's N-GPU loop) with 3 frames in flight over gloo: a fake render writes the rank's strip of
-    a known frame; 8 frames, so every wire buffer is reused; rank 0 must get every frame back, in order."""
+    """dist.ShardedFrames (bench.py's N-GPU loop) with 1, 3 and 6 (bench.py's default) frames in flight over gloo: a fake render writes
+    the rank's strip of a known frame; 14 frames, so every wire buffer is reused; rank 0 must get every frame back, in order."""
     import sys
 
     sys.path.insert(0, REPO)
@@ -62,14 +62,14 @@ def _pipeline_worker(rank, world, port, H, W, q):
     from gsr_amd import dist as gdist
 
     g = torch.Generator().manual_seed(99)
-    truth = [torch.rand((H, W, 3), generator=g) for _ in range(8)]
+    truth = [torch.rand((H, W, 3), generator=g) for _ in range(14)]
     plan = gdist.TileRowPlan(H, W, world)
 
     def render(slot, frame_index, strip):
         strip.copy_(plan.split(truth[frame_index], rank)[: strip.shape[0]])
 
     ok = True
-    for slots in (1, 3):
+    for slots in (1, 3, 6):
         sf = gdist.ShardedFrames(plan, rank, "cpu", slots, render)
         got = []
         for i in range(len(truth)):
