@@ -316,8 +316,9 @@ __global__ __launch_bounds__(PRE_THREADS, (SH16 && !DEBUG) ? 6 : 4) void preproc
 // T = J A (:224-232), so its trace is at most |A|^2 smax^2 (|J_0|^2 + |J_1|^2) + 0.6, its largest eigenvalue at most ~the
 // trace (det >= 0 up to rounding; the 0.1 floor of :172 adds < 0.32), and the radius at most 3 sqrt(.) + 1 (ceil).  Padded
 // by 2 % + 1.5 px against fp32 rounding.  The final tile rows are a subset of the reference rect's rows, which are a subset
-// of [floor((my - Rb) / 16), floor((my + Rb + 15) / 16)]; if no row of this rank lies in there the gaussian cannot reach
-// it.  Anything non-finite stays a candidate.  (Property-tested against row_step = 1: shards reassemble bit-exactly.)
+// of [floor((my - Rb) / 16), floor((my + Rb + 15) / 16)] and of the frame's [0, tiles_y); if no row of this rank lies in there
+// the gaussian cannot reach it, and neither can one whose columns [mx - Rb, mx + Rb + 15] miss the frame (16 px of slack).
+// Anything non-finite stays a candidate.  (Property-tested against row_step = 1: shards reassemble bit-exactly.)
 constexpr int SHARD_PER = 4, SHARD_SPAN = 256 * SHARD_PER;  // gaussians per thread / per workgroup in phase 1
 
 // Stable append of the flagged threads' items to an LDS list, in thread order.  Returns this thread's position (valid when
@@ -357,7 +358,8 @@ __global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, Cam 
     if (threadIdx.x == 0) { s_ncand = 0; s_nvis = 0; }
     const int64_t base = (int64_t)blockIdx.x * SHARD_SPAN;
     const float *V = cam.V, *F = cam.F;
-    const float Hf = (float)cam.H;
+    const float Wf = (float)cam.W, Hf = (float)cam.H;
+    const int tiles_y = (cam.H + GSR_TILE - 1) / GSR_TILE;
 
     // ---- phase 1: the bound.  id = base + r * 256 + thread, appended round by round: the list is in id order ----
     float p[SHARD_PER][3], ls[SHARD_PER];
@@ -378,11 +380,12 @@ __global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, Cam 
 #pragma unroll
         for (int j = 0; j < 3; ++j) cm[j] = ((p[r][0] * V[0 + j] + p[r][1] * V[4 + j]) + p[r][2] * V[8 + j]) + V[12 + j];
         bool k = i < sc.n && !(cm[2] < GSR_CULL_Z);
+        const float pt0 = ((p[r][0] * F[0] + p[r][1] * F[4]) + p[r][2] * F[8]) + F[12];
         const float pt1 = ((p[r][0] * F[1] + p[r][1] * F[5]) + p[r][2] * F[9]) + F[13];
         const float pt3 = ((p[r][0] * F[3] + p[r][1] * F[7]) + p[r][2] * F[11]) + F[15];
         const float p_w = 1.0f / (pt3 + 0.0000001f);
-        const float ndc_y = pt1 * p_w;
-        const float my = ((ndc_y + 1.0f) * Hf - 1.0f) / 2.0f;
+        const float ndc_x = pt0 * p_w, ndc_y = pt1 * p_w;
+        const float mx = ((ndc_x + 1.0f) * Wf - 1.0f) / 2.0f, my = ((ndc_y + 1.0f) * Hf - 1.0f) / 2.0f;
         const float iz = 1.0f / cm[2];
         const float u = fminf(cam.limx, fmaxf(-cam.limx, cm[0] * iz)), v = fminf(cam.limy, fmaxf(-cam.limy, cm[1] * iz));
         const float jx = cam.fx * iz, jy = cam.fy * iz;
@@ -390,11 +393,13 @@ __global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, Cam 
         const float trb = cam.w_sigma2 * smax * (jx * jx * (1.0f + u * u) + jy * jy * (1.0f + v * v)) + 0.6f;
         const float Rb = 3.0f * sqrtf(1.02f * trb + 0.4f) + 1.5f;
         if (k && Rb < 1.0e8f && fabsf(my) < 1.0e8f) {
-            const int lo = max((int)floorf((my - Rb) * 0.0625f), 0), hi = (int)floorf((my + Rb + 15.0f) * 0.0625f);
+            const int lo = max((int)floorf((my - Rb) * 0.0625f), 0), hi = min((int)floorf((my + Rb + 15.0f) * 0.0625f), tiles_y - 1);
             int rr = (lo - row_begin) % row_step;
             if (rr < 0) rr += row_step;
             const int first = rr == 0 ? lo : lo + (row_step - rr);
             if (first > hi) k = false;
+            // columns: a rect that lies left or right of the frame clamps to zero width (covering_bbox + the pixel clamp)
+            if (fabsf(mx) < 1.0e8f && (mx + Rb + 16.0f < 0.0f || mx - Rb - 16.0f > Wf)) k = false;
         }
         const uint32_t pos = block_append_256(k, s_wave, &s_ncand);
         if (k) s_cand[pos] = (uint32_t)i;
