@@ -316,8 +316,9 @@ __global__ __launch_bounds__(PRE_THREADS, (SH16 && !DEBUG) ? 6 : 4) void preproc
 // T = J A (:224-232), so its trace is at most |A|^2 smax^2 (|J_0|^2 + |J_1|^2) + 0.6, its largest eigenvalue at most ~the
 // trace (det >= 0 up to rounding; the 0.1 floor of :172 adds < 0.32), and the radius at most 3 sqrt(.) + 1 (ceil).  Padded
 // by 2 % + 1.5 px against fp32 rounding.  The final tile rows are a subset of the reference rect's rows, which are a subset
-// of [floor((my - Rb) / 16), floor((my + Rb + 15) / 16)] and of the frame's [0, tiles_y); if no row of this rank lies in there
-// the gaussian cannot reach it, and neither can one whose columns [mx - Rb, mx + Rb + 15] miss the frame (16 px of slack).
+// of [floor((my - Rb) / 16), floor((my + Rb + 15) / 16)) — the reference rect ends BEFORE tile row tb3 (pixel rows < 16 tb3,
+// rasterize.py:271-272, :415-418) — and of the frame's [0, tiles_y); if no row of this rank lies in there the gaussian cannot
+// reach it, and neither can one whose columns, bounded the same way, miss the frame.
 // Anything non-finite stays a candidate.  (Property-tested against row_step = 1: shards reassemble bit-exactly.)
 constexpr int SHARD_PER = 4, SHARD_SPAN = 256 * SHARD_PER;  // gaussians per thread / per workgroup in phase 1
 
@@ -393,13 +394,13 @@ __global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, Cam 
         const float trb = cam.w_sigma2 * smax * (jx * jx * (1.0f + u * u) + jy * jy * (1.0f + v * v)) + 0.6f;
         const float Rb = 3.0f * sqrtf(1.02f * trb + 0.4f) + 1.5f;
         if (k && Rb < 1.0e8f && fabsf(my) < 1.0e8f) {
-            const int lo = max((int)floorf((my - Rb) * 0.0625f), 0), hi = min((int)floorf((my + Rb + 15.0f) * 0.0625f), tiles_y - 1);
+            const int lo = max((int)floorf((my - Rb) * 0.0625f), 0), hi = min((int)floorf((my + Rb + 15.0f) * 0.0625f) - 1, tiles_y - 1);
             int rr = (lo - row_begin) % row_step;
             if (rr < 0) rr += row_step;
             const int first = rr == 0 ? lo : lo + (row_step - rr);
             if (first > hi) k = false;
             // columns: a rect that lies left or right of the frame clamps to zero width (covering_bbox + the pixel clamp)
-            if (fabsf(mx) < 1.0e8f && (mx + Rb + 16.0f < 0.0f || mx - Rb - 16.0f > Wf)) k = false;
+            if (fabsf(mx) < 1.0e8f && (mx + Rb < 0.0f || mx - Rb - 16.0f > Wf)) k = false;
         }
         const uint32_t pos = block_append_256(k, s_wave, &s_ncand);
         if (k) s_cand[pos] = (uint32_t)i;
