@@ -12,13 +12,8 @@
  *   - all device work is enqueued on the caller's hipStream_t (passed as void*); nothing synchronises
  *     except gsr_read_stats.
  *   - fp32 throughout (the reference's arithmetic type); device pointers unless marked [host].
- *   - four environment switches exist, for A/B timing and tests only (same frames either way): GSR_FINE_BINNING=1 (read per
- *     call) generates the (gaussian, tile) pairs per 16x16 tile directly instead of per 32x32 cell (csrc/binning.hip);
- *     GSR_SHARD_PREPROCESS=0/1 (read once per process) forces the whole-frame / the three-phase preprocess for tile-row
- *     shards instead of choosing by tile_row_step (csrc/preprocess.hip); GSR_BLEND_PIPE_TILES=n (read once per process)
- *     moves the tile count up to which the blend uses its pipelined one-quadrant walk (default 1280; 0 = never; csrc/blend.hip);
- *     GSR_SH_DENSE=n (read once per process) the number of visible gaussians from which a wave of the preprocess fetches its 64 SH
- *     rows whole through LDS (default 48; 65 = never; csrc/preprocess.hip).
+ *   - no environment variable is read anywhere: the A/B switches of rounds 1-3 are GsrOptions fields since 0.5.0
+ *     (fine_binning, shard_preprocess, blend_pipe_tiles, sh_dense_min) — same frames whatever they say.
  */
 #ifndef GSR_H
 #define GSR_H
@@ -30,7 +25,8 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 400 /* 0.4.0: GsrOptions.keep_flags, GsrOptions.accum_dtype; GsrStats.sort_passes reports the worst frame when the bound was exceeded; blend_impl 2
+#define GSR_VERSION 500 /* 0.5.0: GsrOptions.saturation_rule (the exact colour-saturation early-out), the four environment switches became GsrOptions
+                            fields (the library reads no environment and holds no function statics), + gsr_scene_order.  0.4.0: GsrOptions.keep_flags, GsrOptions.accum_dtype; GsrStats.sort_passes reports the worst frame when the bound was exceeded; blend_impl 2
                             (matrix-pipe experiment) removed; the frame clear covers every word of the control block.  0.3.0: GsrOptions.depth_sort_passes, GsrStats.sort_passes, GSR_ERR_SORT_PASSES.  0.2.1: + gsr_render_batch_slots.
                             0.2.0: gsr_preprocess_geometry/_color removed (measured slower), gsr_read_stats takes a non-const workspace */
 
@@ -84,9 +80,9 @@ typedef struct GsrOptions {
     int32_t reference_compat; /* 1 (default): reproduce Q1 (column W-1 / row H-1 never drawn, rasterize.py:271-272,
                                  :415-418) and Q2 (skip if ANY conic entry == 0, :441).  0: draw every pixel. */
     float early_out_T;        /* a wave of 64 pixels stops once all their transmittances are <= this.  0 (default) is
-                                 exact — identical bits to blending every gaussian like the reference (Q5), because
-                                 T == 0.0f makes every later contribution exactly zero.  >0 is a bounded
-                                 approximation (INRIA uses 1e-4). */
+                                 exact — identical bits to blending every gaussian like the reference (Q5); see
+                                 saturation_rule for what "exact" stops on.  >0 is a bounded approximation (INRIA
+                                 uses 1e-4). */
     int32_t tile_row_begin;   /* multi-GPU sharding: this call bins+blends tile rows begin, begin+step, ... */
     int32_t tile_row_step;    /* default 0 / 1 = all rows */
     int32_t output_layout;    /* 0 (default): image [H,W,3] (= screen.transpose(1,0), rasterize.py:471);
@@ -120,6 +116,23 @@ typedef struct GsrOptions {
                                  GsrStats.overflow, the largest D, the most depth-sort passes), so ONE gsr_read_stats after a run of
                                  unchecked frames — first frame 0, the rest 1 — reports whether ANY of them exceeded max_pairs or
                                  depth_sort_passes.  The views of gsr_render_batch are chained this way internally. */
+    int32_t saturation_rule;  /* when may a quadrant of 64 pixels stop EXACTLY (early_out_T = 0)?
+                                 0 (default): once no later gaussian can change a bit of its COLOUR: every pixel has
+                                 T <= 2^-25 * min(Cr, Cg, Cb).  The update is C = fma(w, c, C) with w = fl(alpha T) <= T and c <= 1 (Q7),
+                                 so w c <= T < ulp(C) / 2 for each channel and the fma returns C unchanged, now and ever after (T only
+                                 shrinks).  Pixels the reference never draws (Q1) count as finished.  Frames are bit-identical to rule 1;
+                                 ~4x fewer evaluated entries on the bench frame.  When out_final_T is requested rule 1 applies (T itself
+                                 is then an output and keeps shrinking).
+                                 1: once T has underflowed to 0.0f for all 64 pixels (rounds 1-3) — the A/B reference of rule 0. */
+    int32_t fine_binning;     /* 0 (default): (gaussian, 32x32 cell) pairs whenever the frame allows (<= 4096 px, n <= 2^28), the blend filters
+                                 the cell lists by tile.  1: (gaussian, 16x16 tile) pairs — the path wider frames always take; A/B timing and
+                                 the test that both build the same frame (csrc/binning.hip).  Was GSR_FINE_BINNING. */
+    int32_t shard_preprocess; /* tile-row shards only: 0 (default) = the three-phase shard preprocess from tile_row_step 5 on, 1 = always the
+                                 whole-frame kernel, 2 = always the three-phase kernel (csrc/preprocess.hip).  Was GSR_SHARD_PREPROCESS. */
+    int32_t blend_pipe_tiles; /* tile count up to which the blend runs its pipelined one-quadrant walk: 0 (default) = 1280, -1 = never
+                                 (csrc/blend.hip).  Was GSR_BLEND_PIPE_TILES. */
+    int32_t sh_dense_min;     /* visible gaussians per wave from which the preprocess fetches the wave's 64 SH rows whole through LDS:
+                                 0 (default) = 48, 65 = never (csrc/preprocess.hip).  Was GSR_SH_DENSE. */
 } GsrOptions;
 
 /* Counters of one frame (device -> host with gsr_read_stats). */

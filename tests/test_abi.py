@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} declared in include/gsr.h but not exported by libgsr.so"
     assert sorted(_lib.EXPORTS) == names
-    assert _lib.lib.gsr_version() == 400
+    assert _lib.lib.gsr_version() == 500
 
 
 def test_struct_sizes_match_header():
@@ -31,7 +31,8 @@ def test_struct_sizes_match_header():
 
     assert C.sizeof(_lib.GsrScene) == 56
     assert C.sizeof(_lib.GsrCamera) == 4 * (16 + 16 + 3 + 6) + 8
-    assert C.sizeof(_lib.GsrOptions) == 48 and _lib.GsrOptions.keep_flags.offset == 44 and _lib.GsrOptions.accum_dtype.offset == 40
+    assert C.sizeof(_lib.GsrOptions) == 68 and _lib.GsrOptions.keep_flags.offset == 44 and _lib.GsrOptions.accum_dtype.offset == 40
+    assert _lib.GsrOptions.saturation_rule.offset == 48 and _lib.GsrOptions.sh_dense_min.offset == 64
     assert C.sizeof(_lib.GsrStats) == 40 and _lib.GsrStats.wave_entries.offset == 24 and _lib.GsrStats.fetched_entries.offset == 32
     assert C.sizeof(_lib.GsrDebugOut) == 72
 
@@ -95,3 +96,14 @@ def test_the_blend_walk_in_the_source_is_what_its_generator_prints():
     out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_blend_walk.py")], capture_output=True, text=True, check=True).stdout
     src = open(os.path.join(REPO, "torch-gaussian-splatting-rasterizer_amd", "csrc", "blend.hip")).read()
     assert out.rstrip("\n") in src
+
+
+def test_the_library_reads_no_environment_and_keeps_no_function_statics():
+    """include/gsr.h: "holds no global state".  The A/B switches of rounds 1-3 were environment variables, three of them read once
+    per process into function statics; since ABI 0.5.0 they are GsrOptions fields."""
+    pkg = os.path.join(REPO, "torch-gaussian-splatting-rasterizer_amd", "csrc")
+    for f in sorted(os.listdir(pkg)):
+        if f.endswith((".hip", ".h")):
+            text = re.sub(r"//.*", "", open(os.path.join(pkg, f)).read())
+            assert "getenv" not in text, f
+            assert not re.search(r"\bstatic\s+(const\s+)?(int|bool|float|unsigned|uint32_t)\s+\w+\s*=\s*\[", text), f

@@ -286,8 +286,9 @@ def test_pair_overflow_is_reported_and_recovered(G):
 
 
 def test_saturation_early_out_is_exact(G):
-    """early_out_T = 0 stops a wave when all its pixels have T == 0.0f; a negative threshold never stops.
-    An opaque wall in front of a long list makes the early-out fire; the frames must be identical."""
+    """The T == 0.0f rule (saturation_rule = 1; also what runs whenever the final T is requested): early_out_T = 0 stops a wave
+    when all its pixels have T == 0.0f; a negative threshold never stops.  An opaque wall in front of a long list makes the
+    early-out fire; the frames must be identical."""
     cols, cam, _ = _medium(G, n=300_000, shift=1.6)
     cols["opacity"] = np.full_like(cols["opacity"], 6.0)        # sigmoid(6) = 0.9975 -> alpha capped at 0.99
     R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
@@ -296,6 +297,75 @@ def test_saturation_early_out_is_exact(G):
     b, Tb = R.render(cam, G.renderer.make_options(early_out_T=-1.0), return_T=True)
     assert torch.equal(a, b) and torch.equal(Ta, Tb)
     assert (Ta == 0).any() and early < R.last_stats["wave_entries"]
+    everything = R.last_stats["wave_entries"]
+    # the same three without the T output: blend everything (rule 1, never stops) == T underflow rule == colour-saturation rule
+    c = R.render(cam, G.renderer.make_options(early_out_T=-1.0, saturation_rule=1))
+    assert torch.equal(c, a) and R.last_stats["wave_entries"] == everything
+    d = R.render(cam, G.renderer.make_options(saturation_rule=1))
+    assert torch.equal(d, a) and R.last_stats["wave_entries"] == early
+    e = R.render(cam)
+    assert torch.equal(e, a) and R.last_stats["wave_entries"] < early
+    print(f"\nopaque wall: evaluated (quadrant, entry) pairs: blend everything {everything}, T == 0 rule {early}, "
+          f"colour rule {R.last_stats['wave_entries']}")
+
+
+def _rule_cases(G):
+    """(name, columns, camera): frames that exercise every blend kernel variant (two quadrants per wave from 3000 tiles, the
+    pipelined one-quadrant walk up to 1280, the plain one-quadrant walk between) and the fixtures' edge cases."""
+    out = [("medium 640x360", *_medium(G)[:2]), ("dense 640x360", *_medium(G, n=300_000, shift=1.6, pose=7)[:2]),
+           ("960x540", *_medium(G, n=250_000, shift=1.4, W=960, H=540, pose=4)[:2]),
+           ("1080p", *_medium(G, n=600_000, seed=360, shift=0.8, W=1920, H=1080, pose=0)[:2]),
+           ("odd 333x197", *_medium(G, n=50_000, W=333, H=197, pose=9)[:2])]
+    wall = _medium(G, n=300_000, shift=1.6)
+    wall[0]["opacity"] = np.full_like(wall[0]["opacity"], 6.0)
+    out.append(("opaque wall", wall[0], wall[1]))
+    for name, prefix in (("f2_small.npz", ""), ("f3_edge.npz", "a_"), ("f3_edge.npz", "b_")):
+        g = load_golden(name)
+        out.append((name + prefix, golden_columns(g), _cams(G, g, prefix)[0]))
+    # f5: the deep-stack fuzz case (hundreds of semi-transparent layers per pixel), rebuilt from its seed like its own test does
+    import os
+    import sys
+
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import fuzz_parity
+
+    g = load_golden("f5_deep_stack.npz")
+    c = fuzz_parity.build_case(int(g["case_seed"]), int(g["max_n"]))
+    out.append(("f5_deep_stack", c["packed"], G.renderer.make_camera(*c["args"])))
+    return out
+
+
+def test_colour_saturation_rule_is_exact(G):
+    """GsrOptions.saturation_rule = 0 (default): a quadrant stops once T <= 2^-25 min(Cr, Cg, Cb) for all its pixels — every later
+    C = fma(w, c, C) has w c <= T < ulp(C) / 2 and returns C (blend_args.h, pixel_finished).  Must be bit-identical to rule 1
+    (stop at T == 0.0f) and to blending every entry: whole frames through all three walk kernels and the plain one, shards, the
+    bf16 store, bf16 accumulators, non-compat, both layouts, culling off, fine binning, progressive prefixes.  And it must
+    remove work wherever rule 1 did."""
+    mk = G.renderer.make_options
+    saved = []
+    for name, cols, cam in _rule_cases(G):
+        scene = G.renderer.GaussianScene.from_packed(cols) if "means" in cols else G.renderer.GaussianScene.from_columns(cols)
+        R = G.renderer.Rasterizer(scene)
+        every = R.render(cam, mk(early_out_T=-1.0, saturation_rule=1))
+        n_every = R.last_stats["wave_entries"]
+        for kw in (dict(), dict(blend_impl=1), dict(tile_row_begin=2, tile_row_step=5, output_layout=2), dict(tile_row_begin=1, tile_row_step=2, output_layout=2),
+                   dict(output_bf16=True), dict(accum_bf16=True), dict(reference_compat=False), dict(output_layout=1),
+                   dict(no_footprint_cull=True), dict(fine_binning=True), dict(draw_limit=997), dict(blend_pipe_tiles=-1),
+                   dict(blend_pipe_tiles=1 << 30)):
+            a = R.render(cam, mk(saturation_rule=1, **kw))
+            n1 = R.last_stats["wave_entries"]
+            b = R.render(cam, mk(**kw))
+            n0 = R.last_stats["wave_entries"]
+            assert torch.equal(a, b), (name, kw)
+            assert n0 <= n1, (name, kw, n0, n1)
+            if not kw:
+                assert torch.equal(b, every) and n1 <= n_every, name
+                saved.append((name, n_every, n1, n0))
+    print()
+    for name, n_every, n1, n0 in saved:
+        print(f"{name:>22}: evaluated (quadrant, entry) pairs: everything {n_every}, T == 0 rule {n1}, colour rule {n0}")
+    assert any(n0 < n1 for _, _, n1, n0 in saved)
 
 
 def test_early_out_is_a_bounded_approximation(G):
@@ -784,52 +854,67 @@ def test_hand_scheduled_blend_walk_equals_the_plain_kernel(G):
     counts must be identical bit for bit — whole frames, shards, early-out, bf16 store, non-compat, the
     fixtures with their edge cases (a frame-covering gaussian, the 0.99 cap, frames not a multiple of 16)."""
     mk = G.renderer.make_options
-    cases = [_medium(G)[:2], _medium(G, n=300_000, shift=1.6, pose=7)[:2]]
+    # 640x360: the pipelined one-quadrant walk; 960x540 (2040 tiles): the plain one-quadrant walk; 1080p: two quadrants per wave
+    # (and its tile_row_step = 4 shard: 2040 tiles again)
+    cases = [_medium(G)[:2], _medium(G, n=300_000, shift=1.6, pose=7)[:2], _medium(G, n=250_000, shift=1.4, W=960, H=540, pose=4)[:2],
+             _medium(G, n=400_000, seed=360, shift=0.8, W=1920, H=1080, pose=0)[:2]]
     for name, prefix in (("f2_small.npz", ""), ("f3_edge.npz", "a_"), ("f3_edge.npz", "b_")):
         g = load_golden(name)
         cases.append((golden_columns(g), _cams(G, g, prefix)[0]))
     for cols, cam in cases:
         R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
         for kw in (dict(), dict(early_out_T=1e-4), dict(tile_row_begin=2, tile_row_step=5, output_layout=2), dict(output_bf16=True),
-                   dict(reference_compat=False), dict(output_layout=1), dict(no_footprint_cull=True)):
+                   dict(reference_compat=False), dict(output_layout=1), dict(no_footprint_cull=True),
+                   dict(tile_row_begin=1, tile_row_step=4, output_layout=2)):
+            # without the T output the colour-saturation rule runs (GsrOptions.saturation_rule): same frames, same counts
+            c = R.render(cam, mk(**kw))
+            sc = dict(R.last_stats)
+            d = R.render(cam, mk(blend_impl=1, **kw))
+            assert torch.equal(c, d), kw
+            assert all(sc[k] == R.last_stats[k] for k in sc if k != "fetched_entries") and sc["fetched_entries"] <= R.last_stats["fetched_entries"], kw
             a, Ta = R.render(cam, mk(**kw), return_T=True)
             sa = dict(R.last_stats)
             b, Tb = R.render(cam, mk(blend_impl=1, **kw), return_T=True)
             assert torch.equal(a, b) and torch.equal(Ta, Tb), kw
+            assert "early_out_T" in kw or torch.equal(a, c), kw  # (an approximate threshold stops the two rules' quadrants at different entries)
             sb = R.last_stats
             # same lists, same evaluations; the product kernel stages 128 entries per batch, the plain one 256, so a tile that
             # saturates stops fetching a little earlier in the former
             assert all(sa[k] == sb[k] for k in sa if k != "fetched_entries") and sa["fetched_entries"] <= sb["fetched_entries"], kw
 
 
-@pytest.mark.parametrize("name,prefix", [("medium", ""), ("f3_edge.npz", "a_"), ("f3_edge.npz", "b_")])
-def test_coarse_binning_builds_the_same_frame_as_fine_binning(G, monkeypatch, name, prefix):
+@pytest.mark.parametrize("name,prefix", [("medium", ""), ("960x540", ""), ("f3_edge.npz", "a_"), ("f3_edge.npz", "b_")])
+def test_coarse_binning_builds_the_same_frame_as_fine_binning(G, name, prefix):
     """binning.hip: pairs are generated and sorted per 32x32 cell, and the blend of a tile keeps the cell-list entries that carry
-    its bit (blend.hip, TileList); with GSR_FINE_BINNING=1 pairs are generated per tile directly (the path frames wider than
+    its bit (blend.hip, TileList); with GsrOptions.fine_binning = 1 pairs are generated per tile directly (the path frames wider than
     4096 px always take).  Every tile walks the same gaussians in the same order up to entries whose footprint misses the tile (coarser emit-time culling keeps
     a few more; the blend's quadrant test rejects them): frames, T and the evaluated count must be identical — whole frame,
     shards (odd and even steps), progressive prefixes, culling off, a frame-covering gaussian (f3a), a frame that is not a
     multiple of 16 or 32 (f3b)."""
     if name == "medium":
         cols, cam, _ = _medium(G, n=150_000, W=650, H=370)
+    elif name == "960x540":  # 2040 tiles: the one-quadrant walk without the pipelining (blend_walk_kernel<1, false>)
+        cols, cam, _ = _medium(G, n=250_000, shift=1.4, W=960, H=540, pose=4)
     else:
         g = load_golden(name)
         cols = golden_columns(g)
         cam, _ = _cams(G, g, prefix)
     R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
     mk = G.renderer.make_options
-    variants = [mk(), mk(tile_row_begin=1, tile_row_step=3, output_layout=2), mk(tile_row_begin=3, tile_row_step=8, output_layout=2),
-                mk(draw_limit=37), mk(no_footprint_cull=True), mk(reference_compat=False)]
+    variants = [dict(), dict(tile_row_begin=1, tile_row_step=3, output_layout=2), dict(tile_row_begin=3, tile_row_step=8, output_layout=2),
+                dict(draw_limit=37), dict(no_footprint_cull=True), dict(reference_compat=False)]
     coarse = []
-    for o in variants:
-        img, T = R.render(cam, o, return_T=True)
-        coarse.append((img.clone(), T.clone(), dict(R.last_stats)))
-    monkeypatch.setenv("GSR_FINE_BINNING", "1")
-    for o, (img, T, st) in zip(variants, coarse):
-        fimg, fT = R.render(cam, o, return_T=True)
-        assert torch.equal(fimg, img) and torch.equal(fT, T)
+    for kw in variants:
+        img, T = R.render(cam, mk(**kw), return_T=True)
+        st = dict(R.last_stats)
+        coarse.append((img.clone(), T.clone(), st, R.render(cam, mk(**kw)).clone(), R.last_stats["wave_entries"]))
+    for kw, (img, T, st, img0, ev0) in zip(variants, coarse):
+        fimg, fT = R.render(cam, mk(fine_binning=True, **kw), return_T=True)
+        assert torch.equal(fimg, img) and torch.equal(fT, T) and torch.equal(img0, img)
         # the lists may differ in entries that touch no pixel of their tile (the two paths cull at emission on different
         # rectangles); what the blend evaluates after its exact per-quadrant test is the same
         assert R.last_stats["n_visible"] == st["n_visible"] and R.last_stats["wave_entries"] == st["wave_entries"]
-    monkeypatch.delenv("GSR_FINE_BINNING")
+        # the colour-saturation rule (no T output) tests per 64 LIST entries: entries that touch no pixel shift the chunk
+        # boundaries, so the counts may differ a little between the two lists — the frames may not
+        assert torch.equal(R.render(cam, mk(fine_binning=True, **kw)), img)
     assert torch.equal(R.render(cam), coarse[0][0])

@@ -114,12 +114,9 @@ def main():
             assert torch.equal(R.render(cam), img), "not reproducible"
             assert torch.equal(R.render(cam, mk(no_footprint_cull=True)), img), "culling changes bits"
             assert torch.equal(R.render(cam, mk(blend_impl=1)), img), "asm walk differs from the plain blend kernel"
-            os.environ["GSR_FINE_BINNING"] = "1"
-            try:
-                fine = R.render(cam)
-            finally:
-                del os.environ["GSR_FINE_BINNING"]
-            assert torch.equal(fine, img), "coarse and fine binning differ"
+            assert torch.equal(R.render(cam, mk(fine_binning=True)), img), "coarse and fine binning differ"
+            assert torch.equal(R.render(cam, mk(saturation_rule=1)), img), "colour-saturation rule differs from the T == 0 rule"
+            assert torch.equal(R.render(cam, mk(saturation_rule=1, early_out_T=-1.0)), img), "early-out differs from blending everything"
             assert torch.equal(R.render(cam, mk(output_bf16=True)), img.to(torch.bfloat16)), "bf16 store"
             step = int(rng.choice([2, 3, 5, 8]))
             tiles_y = (H + 15) // 16

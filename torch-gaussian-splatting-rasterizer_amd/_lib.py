@@ -82,6 +82,11 @@ class GsrOptions(C.Structure):
         ("depth_sort_passes", C.c_int32),
         ("accum_dtype", C.c_int32),
         ("keep_flags", C.c_int32),
+        ("saturation_rule", C.c_int32),
+        ("fine_binning", C.c_int32),
+        ("shard_preprocess", C.c_int32),
+        ("blend_pipe_tiles", C.c_int32),
+        ("sh_dense_min", C.c_int32),
     ]
 
 

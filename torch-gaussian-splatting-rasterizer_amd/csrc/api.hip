@@ -88,6 +88,11 @@ static int check_frame(int64_t n, const GsrCamera *cam, const GsrOptions *opts, 
     if (opts->depth_sort_passes < 0 || opts->depth_sort_passes > 4) { set_error("bad depth_sort_passes %d", opts->depth_sort_passes); return GSR_ERR_BAD_ARG; }
     if (opts->accum_dtype != 0 && opts->accum_dtype != 1) { set_error("bad accum_dtype %d", opts->accum_dtype); return GSR_ERR_BAD_ARG; }
     if (opts->keep_flags != 0 && opts->keep_flags != 1) { set_error("bad keep_flags %d", opts->keep_flags); return GSR_ERR_BAD_ARG; }
+    if (opts->saturation_rule != 0 && opts->saturation_rule != 1) { set_error("bad saturation_rule %d", opts->saturation_rule); return GSR_ERR_BAD_ARG; }
+    if (opts->fine_binning != 0 && opts->fine_binning != 1) { set_error("bad fine_binning %d", opts->fine_binning); return GSR_ERR_BAD_ARG; }
+    if (opts->shard_preprocess < 0 || opts->shard_preprocess > 2) { set_error("bad shard_preprocess %d", opts->shard_preprocess); return GSR_ERR_BAD_ARG; }
+    if (opts->blend_pipe_tiles < -1) { set_error("bad blend_pipe_tiles %d", opts->blend_pipe_tiles); return GSR_ERR_BAD_ARG; }
+    if (opts->sh_dense_min < 0 || opts->sh_dense_min > 65) { set_error("bad sh_dense_min %d", opts->sh_dense_min); return GSR_ERR_BAD_ARG; }
     if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) { set_error("workspace must be 256-byte aligned"); return GSR_ERR_BAD_ARG; }
     const size_t need = carve_workspace(workspace, n, cam->width, cam->height, max_pairs, ws);
     if (workspace_bytes < need) {
@@ -259,7 +264,7 @@ int gsr_blend(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t m
     Workspace ws;
     int rc = check_frame(n, cam, opts, max_pairs, workspace, workspace_bytes, &ws);
     if (rc) return rc;
-    return launch_blend(*cam, *opts, ws, tile_lists(ws), out_image, out_final_T, static_cast<hipStream_t>(stream));
+    return launch_blend(*cam, *opts, ws, tile_lists(ws, *opts), out_image, out_final_T, static_cast<hipStream_t>(stream));
 }
 
 static int render_forward_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,

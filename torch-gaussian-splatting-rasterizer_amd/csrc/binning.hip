@@ -204,9 +204,9 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
                                                                  const uint32_t *__restrict__ r8_a, const uint32_t *__restrict__ r8_b,
                                                                  const FrameCtrl *ctrl, const ushort4 *__restrict__ rect, Shard sh,
                                                                  int bits_x, int tiles_y, const GaussRec *__restrict__ rec,
-                                                                 const uint32_t *__restrict__ blk_off, uint32_t max_pairs,
+                                                                 const uint32_t *blk_off, uint32_t max_pairs,
                                                                  uint32_t *__restrict__ pkey, uint32_t *__restrict__ pval,
-                                                                 uint32_t draw_limit, Shard tsh, uint32_t *__restrict__ blk_entries)
+                                                                 uint32_t draw_limit, Shard tsh, uint32_t *blk_entries /* = blk_off: no __restrict__ on either */)
 {
     __shared__ uint32_t scratch[8];
     __shared__ uint32_t s_off[EMIT_THREADS];   // exclusive pair offset of each gaussian inside the workgroup
@@ -335,16 +335,12 @@ static int ceil_log2(int v)
 }
 
 // Coarse binning when the packed rect exists (frames up to 4096 px) and the gaussian ids leave four bits for the tile mask.
-// GSR_FINE_BINNING=1 forces the fine path (A/B timing, and the test that both build the same frame).
-TileKeying tile_keying(const Workspace &ws)
+// GsrOptions.fine_binning = 1 forces the fine path (A/B timing, and the test that both build the same frame).
+TileKeying tile_keying(const Workspace &ws, const GsrOptions &opts)
 {
     TileKeying k;
     static_assert(COARSE_ID_BITS == 28, "coarse_capable() in gsr_internal.h states the same limits");
-    k.coarse = coarse_capable(ws);
-    if (k.coarse) {
-        const char *e = std::getenv("GSR_FINE_BINNING");
-        if (e && e[0] == '1') k.coarse = false;
-    }
+    k.coarse = coarse_capable(ws) && opts.fine_binning == 0;
     k.grid_x = k.coarse ? ws.ctiles_x : ws.tiles_x;
     k.grid_y = k.coarse ? ws.ctiles_y : ws.tiles_y;
     k.bits_x = std::max(1, ceil_log2(k.grid_x));
@@ -357,11 +353,11 @@ TileKeying tile_keying(const Workspace &ws)
 // keeps the entries with its bit while it stages (blend.hip).  Round 2 expanded them into per-tile lists first (pair_expand_kernel:
 // 34 us, 122 MB of traffic, 16 B of workspace per pair slot); A/B in one process on the bench frame: bin + sort 0.375 -> 0.341 ms,
 // blend 0.553 -> 0.565 ms, frames and counters identical.
-bool blend_reads_cell_lists(const Workspace &ws) { return tile_keying(ws).coarse; }
+bool blend_reads_cell_lists(const Workspace &ws, const GsrOptions &opts) { return tile_keying(ws, opts).coarse; }
 
-const uint32_t *tile_lists(const Workspace &ws)
+const uint32_t *tile_lists(const Workspace &ws, const GsrOptions &opts)
 {
-    const TileKeying tk = tile_keying(ws);
+    const TileKeying tk = tile_keying(ws, opts);
     if (ws.n <= 0 || ws.max_pairs <= 0) return ws.pval[0];
     return ws.pval[((tk.bits_x + tk.bits_y + 7) / 8) & 1];  // ping-pong parity of the tile sort's passes
 }
@@ -380,7 +376,7 @@ int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s)
     // each holding exactly one of them; with an odd step (or none) every cell row can hold one.  The expansion keeps only this
     // rank's tiles either way.
     const Shard csh = (sh.step > 1 && sh.step % 2 == 0) ? Shard{sh.begin >> 1, sh.step >> 1} : Shard{0, 1};
-    const TileKeying tk = tile_keying(ws);
+    const TileKeying tk = tile_keying(ws, opts);
     const int n_ctiles = ws.ctiles_x * ws.ctiles_y;
     const uint32_t cap = (uint32_t)ws.max_pairs;
     const uint32_t limit = opts.draw_limit > 0 ? (uint32_t)opts.draw_limit : 0xFFFFFFFFu;

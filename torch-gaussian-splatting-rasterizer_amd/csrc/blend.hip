@@ -12,11 +12,12 @@
 //   - per pixel the reference's arithmetic: power (log2 domain, coefficients pre-scaled in preprocess),
 //     alpha = min(opacity * 2^power, 0.99), contribute iff alpha > 1/255 and power <= 0 (:285-291),
 //     C += alpha * T * rgb, T *= 1 - alpha (:295-303);
-//   - saturation early-out by wave ballot: a quadrant stops once T <= opts.early_out_T holds for all its 64 pixels,
-//     the workgroup stops fetching once every wave has.  The default threshold 0 is EXACT, not an
-//     approximation of the reference's "blend every gaussian" (Q5): transmittance only ever shrinks, and once it
-//     has underflowed to 0.0f (a few dozen near-opaque layers) alpha*T*rgb = 0 and T stays 0 — the remaining
-//     entries cannot change a bit.  early_out_T > 0 (INRIA uses 1e-4) is the usual bounded approximation.
+//   - saturation early-out by wave ballot: a quadrant stops once every one of its 64 pixels is finished (blend_args.h,
+//     pixel_finished), the workgroup stops fetching once every wave has.  The default is EXACT, not an approximation of the
+//     reference's "blend every gaussian" (Q5): a pixel is finished when no later entry can change a bit of its colour — T has
+//     fallen below half an ulp of each colour sum (T <= 2^-25 min C: the single-rounding fma returns C unchanged from then on), or,
+//     GsrOptions.saturation_rule = 1 and whenever the final T is an output, T has underflowed to 0.0f.  early_out_T > 0 (INRIA uses
+//     1e-4) is the usual bounded approximation.  Bench frame: 26.1 M evaluated (quadrant, entry) pairs under the T == 0 rule.
 // Two kernels share this: blend_kernel, the plain-C statement (blend_impl = 1), and blend_walk_kernel, the product, whose
 // inner walk is one hand-scheduled asm statement — bit-identical frames (its comment has the measurements).
 //
@@ -29,7 +30,6 @@
 // + 8 per tile range.  The kernel is bound on-chip, not by HBM: per evaluated (quadrant, entry) ~15 VALU issues incl. one
 // quarter-rate v_exp_f32, and the record's three wave-wide LDS broadcast reads (10 LDS cycles).  bench.py reports the HBM
 // fraction (the contract figure) and, from the committed PMC passes, the VALU issue and LDS busy fractions.
-#include <cstdlib>
 #include "gsr_internal.h"
 #include "blend_args.h"
 #include "footprint.h"
@@ -897,6 +897,7 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
 
     TileList<256> list = tile_list_of<256>(a, tile, tx, ty);
     float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
+    const bool undrawn = a.sat_scale != 0.0f && !(px < a.xlim && py < a.ylim);  // never stored: finished from the start
     bool wave_done = false;
     uint32_t evaluated = 0;  // wave-uniform
     uint32_t fetched = 0;    // workgroup-uniform
@@ -947,7 +948,7 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
                     acc_round(T, Cr, Cg, Cb);
                 }
             }
-            if (__all(T <= a.early_T)) {
+            if (__all(pixel_finished(a, T, Cr, Cg, Cb, undrawn))) {
                 wave_done = true;
                 if (lane == 0) atomicAdd(&s_done, 1);
                 break;
@@ -1013,6 +1014,9 @@ __global__ __launch_bounds__(256 / QPW, PIPE ? 5 : 8) void blend_walk_kernel(Ble
     float TA = 1.0f, CrA = 0.0f, CgA = 0.0f, CbA = 0.0f;
     float TB = 1.0f, CrB = 0.0f, CgB = 0.0f, CbB = 0.0f;
     bool doneA = false, doneB = QPW == 1;  // wave-uniform: quadrant saturated (B does not exist when QPW = 1)
+    // pixels whose colour is never stored (outside the frame / Q1) are finished from the start
+    const bool undrawnA = a.sat_scale != 0.0f && !(px < a.xlim && py < a.ylim);
+    const bool undrawnB = a.sat_scale != 0.0f && !(px + 8 < a.xlim && py < a.ylim);
     uint32_t evaluated = 0;                // wave-uniform
     uint32_t fetched = 0;                  // workgroup-uniform
     if (tid == 0) s_done = 0;
@@ -1054,8 +1058,8 @@ __global__ __launch_bounds__(256 / QPW, PIPE ? 5 : 8) void blend_walk_kernel(Ble
 #else
             TA += __builtin_popcountll(fA) * 1e-9f; TB += __builtin_popcountll(fB) * 1e-9f;
 #endif
-            if (!doneA && __all(TA <= a.early_T)) doneA = true;
-            if (QPW == 2 && !doneB && __all(TB <= a.early_T)) doneB = true;
+            if (!doneA && __all(pixel_finished(a, TA, CrA, CgA, CbA, undrawnA))) doneA = true;
+            if (QPW == 2 && !doneB && __all(pixel_finished(a, TB, CrB, CgB, CbB, undrawnB))) doneB = true;
             if (doneA && doneB) {
                 if (lane == 0) atomicAdd(&s_done, 1);
                 break;
@@ -1095,12 +1099,8 @@ __global__ __launch_bounds__(256 / QPW, PIPE ? 5 : 8) void blend_walk_kernel(Ble
 // two quadrants per wave from this many tiles per launch on (measured: 4080 tiles better with two, 2040 with one); below, one quadrant per wave (see blend_walk_kernel)
 constexpr int BLEND_HALF_MIN_TILES = 3000;
 // the pipelined one-quadrant walk (96 VGPRs: 5 waves per SIMD = 1280 four-wave workgroups resident) up to this many tiles per launch;
-// GSR_BLEND_PIPE_TILES overrides it (experiments: 0 switches the variant off)
-static int blend_pipe_max_tiles()
-{
-    static const int v = [] { const char *e = getenv("GSR_BLEND_PIPE_TILES"); return e ? atoi(e) : 1280; }();
-    return v;
-}
+// GsrOptions.blend_pipe_tiles overrides it (experiments and tests: -1 switches the variant off)
+constexpr int BLEND_PIPE_MAX_TILES = 1280;
 
 int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, const uint32_t *lists, void *out_image,
                  float *out_T, hipStream_t s)
@@ -1109,7 +1109,7 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     a.ranges = ws.ranges;
     a.cranges = ws.cranges;
     a.ctiles_x = ws.ctiles_x;
-    a.cell_lists = blend_reads_cell_lists(ws) ? 1 : 0;
+    a.cell_lists = blend_reads_cell_lists(ws, opts) ? 1 : 0;
     a.pval = lists;
     a.rec = ws.rec;
     a.out = out_image;
@@ -1125,6 +1125,9 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     a.layout = opts.output_layout;
     a.out_bf16 = opts.output_dtype == 1;
     a.early_T = opts.early_out_T;
+    // the colour-saturation rule (blend_args.h) leaves T unfinished: when the caller asks for the final T it is an output like the colour
+    a.sat_scale = (opts.saturation_rule == 0 && out_T == nullptr) ? 0x1p-25f : 0.0f;
+    const int pipe_max_tiles = opts.blend_pipe_tiles == 0 ? BLEND_PIPE_MAX_TILES : opts.blend_pipe_tiles;
     if (a.rows <= 0 || a.tiles_x <= 0) return GSR_OK;
     const int rows_per_xcd = (a.rows + 7) / 8;
     const int slots_per_group = rows_per_xcd * a.tiles_x;
@@ -1136,7 +1139,7 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     if (opts.accum_dtype == 1) hipLaunchKernelGGL(blend_kernel<true>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     else if (opts.blend_impl == 1) hipLaunchKernelGGL(blend_kernel<false>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     else if (a.rows * a.tiles_x >= BLEND_HALF_MIN_TILES) hipLaunchKernelGGL((blend_walk_kernel<2, false>), dim3(8u * (unsigned)slots_per_group), dim3(128), 0, s, a);
-    else if (a.rows * a.tiles_x <= blend_pipe_max_tiles()) hipLaunchKernelGGL((blend_walk_kernel<1, true>), dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
+    else if (a.rows * a.tiles_x <= pipe_max_tiles) hipLaunchKernelGGL((blend_walk_kernel<1, true>), dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((blend_walk_kernel<1, false>), dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     GSR_HIP(hipGetLastError());
     return GSR_OK;

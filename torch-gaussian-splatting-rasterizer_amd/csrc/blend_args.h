@@ -22,7 +22,22 @@ struct BlendArgs {
     int layout;
     int out_bf16;
     float early_T;
+    float sat_scale;      // 2^-25: a pixel is finished once T <= sat_scale * min(Cr, Cg, Cb) (GsrOptions.saturation_rule = 0); 0: only T <= early_T
 };
+
+// Has this pixel stopped changing?  (wave-uniformly combined with __all by the kernels.)
+//   - T <= early_T: the caller's threshold; with 0 it fires once T has underflowed to 0.0f, after which alpha*T*rgb = 0 exactly;
+//   - T <= 2^-25 min(Cr, Cg, Cb): the colour update is one rounding, C = fma(w, c, C), with w = fl(alpha T) <= T (alpha < 1) and
+//     0 <= c <= 1 (Q7), and C in [2^e, 2^(e+1)) has ulp(C) / 2 = 2^(e-24) > 2^-25 C: so w c <= T < ulp(C) / 2 and the fma returns C
+//     bit for bit — for this entry and, T never growing and C never changing, for every later one.  A channel at exactly 0 gives the
+//     threshold 0 (falls back to the T == 0 rule); a denormal threshold is still a valid (smaller) one.
+//   - `undrawn`: a pixel whose colour is never stored (outside the frame, or Q1's last column / row) has nothing left to change.
+__device__ __forceinline__ bool pixel_finished(const BlendArgs &a, float T, float Cr, float Cg, float Cb, bool undrawn)
+{
+    // sat_scale == 0: the caller's threshold alone (a negative one never fires: "blend every entry", the tests' ground truth)
+    const float thr = a.sat_scale != 0.0f ? fmaxf(a.early_T, a.sat_scale * fminf(fminf(Cr, Cg), Cb)) : a.early_T;
+    return undrawn | (T <= thr);
+}
 
 // float -> the nearest bfloat16 (ties to even), as a float.  Values are finite.
 __device__ __forceinline__ float bf16_round(float x)

@@ -124,7 +124,7 @@ struct TileKeying {
     bool coarse;          // pairs are generated and sorted per 32x32 cell; the blend filters the cell lists by tile (binning.hip)
     int grid_x, grid_y;
 };
-TileKeying tile_keying(const Workspace &ws);
+TileKeying tile_keying(const Workspace &ws, const GsrOptions &opts);
 inline bool rect_fits_8bit(const Workspace &ws) { return ws.tiles_x <= 256 && ws.tiles_y <= 256; }
 // Can this frame bin per 32x32 cell (binning.hip)?  Needs the packed rect and pair values of 28 id bits + 4 mask bits.
 inline bool coarse_capable(const Workspace &ws) { return rect_fits_8bit(ws) && ws.n <= ((int64_t)1 << 28); }
@@ -133,15 +133,15 @@ inline bool coarse_capable(const Workspace &ws) { return rect_fits_8bit(ws) && w
 // draws, so they take the whole-frame path.
 inline bool shard_compact(const GsrOptions &o)
 {
-    static const int forced = [] { const char *e = getenv("GSR_SHARD_PREPROCESS"); return e ? atoi(e) : -1; }();  // experiments: 0 / 1
     if (o.tile_row_step <= 1 || o.draw_limit != 0) return false;
-    return forced >= 0 ? forced != 0 : o.tile_row_step >= 5;  // measured: 2 and 4 shards are as fast or faster through the whole-frame kernel
+    if (o.shard_preprocess != 0) return o.shard_preprocess == 2;  // A/B: 1 = whole-frame kernel, 2 = three-phase kernel
+    return o.tile_row_step >= 5;  // measured: 2 and 4 shards are as fast or faster through the whole-frame kernel
 }
 // Stage 2b: pairs of the depth-sorted gaussians -> per-tile depth-ordered lists + ranges[] (count, scan, emit, sort, ranges,
 // and with coarse binning the expansion).
 int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s);
-const uint32_t *tile_lists(const Workspace &ws);  // the array ranges[] / cranges[] index after launch_binning (gaussian ids [| tile mask << 28])
-bool blend_reads_cell_lists(const Workspace &ws);  // coarse binning: the blend filters the 32x32-cell lists by tile bit itself
+const uint32_t *tile_lists(const Workspace &ws, const GsrOptions &opts);  // the array ranges[] / cranges[] index after launch_binning (gaussian ids [| tile mask << 28])
+bool blend_reads_cell_lists(const Workspace &ws, const GsrOptions &opts);  // coarse binning: the blend filters the 32x32-cell lists by tile bit itself
 int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, const uint32_t *lists, void *out_image,
                  float *out_T, hipStream_t s);
 int launch_blend_stats(FrameCtrl *ctrl, size_t workspace_bytes, hipStream_t s);

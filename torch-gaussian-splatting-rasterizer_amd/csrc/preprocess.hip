@@ -521,10 +521,10 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
     if (dbg) d = *dbg;
     const int row_step = opts.tile_row_step < 1 ? 1 : opts.tile_row_step, packed = rect_fits_8bit(ws) ? 1 : 0;
     const bool h16 = scene.sh_dtype == 1;
-    // from how many visible gaussians per wave on the wave's SH rows are fetched whole through LDS (load_sh48_wave); GSR_SH_DENSE
-    // overrides it for experiments (65 = never).  Swept on the bench frame (file order / Morton order): >= 56: 0.273 / 0.216 ms,
+    // from how many visible gaussians per wave on the wave's SH rows are fetched whole through LDS (load_sh48_wave);
+    // GsrOptions.sh_dense_min overrides it for experiments (65 = never).  Swept on the bench frame (file order / Morton order): >= 56: 0.273 / 0.216 ms,
     // >= 48: 0.275 / 0.216, >= 32: 0.359 / 0.202, >= 16: 0.381 / 0.205, never: 0.288 / 0.241.
-    static const int sh_dense_min = [] { const char *e = getenv("GSR_SH_DENSE"); return e ? atoi(e) : 48; }();
+    const int sh_dense_min = opts.sh_dense_min > 0 ? opts.sh_dense_min : 48;
 #define GSR_LAUNCH_PRE(DBG, H16)                                                                                              \
     hipLaunchKernelGGL((preprocess_kernel<DBG, H16>), dim3(grid), dim3(PRE_THREADS), 0, s, scene, k, opts.reference_compat,     \
                        opts.no_footprint_cull, opts.tile_row_begin, row_step, opts.draw_limit > 0 ? 1 : 0, ws.rec, ws.rect,     \

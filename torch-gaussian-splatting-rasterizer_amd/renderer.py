@@ -118,7 +118,9 @@ def make_camera(qvec, tvec, fx_full: float, fy_full: float, cam_width: int, cam_
 
 def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_row_begin: int = 0, tile_row_step: int = 1,
                  output_layout: int = 0, no_footprint_cull: bool = False, blend_impl: int = 0, draw_limit: int = 0,
-                 output_bf16: bool = False, depth_sort_passes: int = 0, keep_flags: bool = False, accum_bf16: bool = False) -> GsrOptions:
+                 output_bf16: bool = False, depth_sort_passes: int = 0, keep_flags: bool = False, accum_bf16: bool = False,
+                 saturation_rule: int = 0, fine_binning: bool = False, shard_preprocess: int = 0, blend_pipe_tiles: int = 0,
+                 sh_dense_min: int = 0) -> GsrOptions:
     o = _lib.default_options()
     o.reference_compat = 1 if reference_compat else 0
     o.early_out_T = float(early_out_T)
@@ -132,6 +134,11 @@ def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_r
     o.depth_sort_passes = int(depth_sort_passes)  # 0: no bound (Rasterizer.render / render_batch fill in what the frames' counters have taught them)
     o.accum_dtype = 1 if accum_bf16 else 0        # configs[2] as worded: bf16 accumulators (measurement option, plain-C kernel)
     o.keep_flags = 1 if keep_flags else 0         # Rasterizer.enqueue sets it itself for the frames after the first since the last stats()
+    o.saturation_rule = int(saturation_rule)      # 0: a quadrant stops once its colour cannot change (exact); 1: once T == 0.0f (the A/B reference)
+    o.fine_binning = 1 if fine_binning else 0     # A/B switches (same frames): per-tile pairs; 1/2 = whole-frame / three-phase shard
+    o.shard_preprocess = int(shard_preprocess)    # preprocess; tile bound of the pipelined blend walk (-1 = never); dense-wave SH threshold
+    o.blend_pipe_tiles = int(blend_pipe_tiles)
+    o.sh_dense_min = int(sh_dense_min)
     return o
 
 
@@ -232,6 +239,15 @@ class Rasterizer:
         check(rc)
         return self.last_stats
 
+    @staticmethod
+    def _incomplete(what: str, stats) -> "_lib.GsrError":
+        """The error of a frame that is still over a bound after every retry: the status the LAST attempt reported
+        (pair overflow before sort passes), never GSR_ERR_BAD_ARG — no argument was bad."""
+        ov = int((stats or {}).get("overflow", 0))
+        if ov & 1 or not ov & 2:
+            return _lib.GsrPairOverflow(_lib.GSR_ERR_PAIR_OVERFLOW, f"{what}: {stats}")
+        return _lib.GsrSortPasses(_lib.GSR_ERR_SORT_PASSES, f"{what}: {stats}")
+
     def _grow_pairs(self, slack_div: int) -> None:
         """After GsrPairOverflow: room for what the worst frame needed, or give up when that cannot be had."""
         need = int(self.last_stats["n_pairs_bbox"])
@@ -268,7 +284,7 @@ class Rasterizer:
                 tried = self.sort_passes
                 continue
             return (img, final_T) if return_T else img
-        raise _lib.GsrError(_lib.GSR_ERR_BAD_ARG, f"frame still incomplete after {MAX_RETRIES} re-renders: {self.last_stats}")
+        raise self._incomplete(f"frame still incomplete after {MAX_RETRIES} re-renders", self.last_stats)
 
     def render_batch(self, cams, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Several views of the resident scene in one call: [B,H,W,3].  Pair buffers and the depth-sort bound are sized on
@@ -291,7 +307,9 @@ class Rasterizer:
         for _ in range(MAX_RETRIES + 1):
             ws = self._workspace(W, H)
             o = GsrOptions.from_buffer_copy(opts if unbounded else self.bounded(opts))
-            o.keep_flags = 0  # view 0 clears the record, libgsr chains the rest: the counters then speak for every view
+            # view 0 clears the record, libgsr chains the rest: the counters then speak for every view — and for the frames
+            # enqueue()d on this workspace and not yet checked, whose record view 0 must then keep
+            o.keep_flags = 1 if self._chained else 0
             check(lib.gsr_render_batch(C.byref(sc), arr, len(cams), C.byref(o), self.max_pairs, ws.data_ptr(), ws.numel(),
                                        out.data_ptr(), H * W * 3, _stream_ptr(self.scene.device)))
             self._chained, self._last_empty = True, False
@@ -304,7 +322,7 @@ class Rasterizer:
                 if opts.depth_sort_passes != 0:
                     raise
                 unbounded = o.depth_sort_passes >= self.sort_passes  # the reported need did not exceed what was enqueued: play safe
-        raise _lib.GsrError(_lib.GSR_ERR_BAD_ARG, f"batch still incomplete after {MAX_RETRIES} re-renders: {self.last_stats}")
+        raise self._incomplete(f"batch still incomplete after {MAX_RETRIES} re-renders", self.last_stats)
 
     def fit_pairs(self, cam: GsrCamera, opts: Optional[GsrOptions] = None, slack: float = 1.25) -> int:
         """Size the pair buffers to this view: one probing frame, then max_pairs = slack * D (+ margin).
@@ -413,6 +431,9 @@ class FramesInFlight:
             st_arr = (C.c_void_p * n)(*[int(st.cuda_stream) for st in self.streams])
             self.set_sort_passes(max(r.sort_passes for r in self.rasterizers))
             o = GsrOptions.from_buffer_copy(opts if unbounded else r0.bounded(opts))
+            for k in range(n):  # frames submit()ted and not yet checked: read (and report) their record before the batch clears it
+                if self.rasterizers[k]._chained:
+                    self.stats(k)
             o.keep_flags = 0  # a slot's first view clears its record, libgsr chains the slot's later views
             check(lib.gsr_render_batch_slots(C.byref(sc), arr, len(cams), C.byref(o), r0.max_pairs, ws_arr, wss[0].numel(), st_arr, n,
                                              out.data_ptr(), H * W * 3))
@@ -439,7 +460,8 @@ class FramesInFlight:
                 self.set_max_pairs(int(min(_lib.GSR_MAX_PAIRS, need + need // 4 + 1024)))
             if short:
                 unbounded = o.depth_sort_passes >= max(r.sort_passes for r in self.rasterizers)  # the need did not grow: play safe
-        raise _lib.GsrError(_lib.GSR_ERR_BAD_ARG, f"batch still incomplete after {MAX_RETRIES} re-renders")
+        raise Rasterizer._incomplete(f"batch still incomplete after {MAX_RETRIES} re-renders",
+                                     max((r.last_stats or {} for r in self.rasterizers), key=lambda d: d.get("overflow", 0)))
 
     def wait(self, slot: int) -> None:
         torch.cuda.current_stream(self.scene.device).wait_stream(self.streams[slot])
