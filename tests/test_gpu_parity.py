@@ -912,9 +912,13 @@ def test_coarse_binning_builds_the_same_frame_as_fine_binning(G, name, prefix):
         fimg, fT = R.render(cam, mk(fine_binning=True, **kw), return_T=True)
         assert torch.equal(fimg, img) and torch.equal(fT, T) and torch.equal(img0, img)
         # the lists may differ in entries that touch no pixel of their tile (the two paths cull at emission on different
-        # rectangles); what the blend evaluates after its exact per-quadrant test is the same
-        assert R.last_stats["n_visible"] == st["n_visible"] and R.last_stats["wave_entries"] == st["wave_entries"]
-        # the colour-saturation rule (no T output) tests per 64 LIST entries: entries that touch no pixel shift the chunk
-        # boundaries, so the counts may differ a little between the two lists — the frames may not
+        # rectangles); what the blend evaluates after its exact per-quadrant test is the same — up to where a saturated quadrant
+        # stops: that is tested per 64 LIST entries, and entries that touch no pixel shift the chunk boundaries (the dense 960x540
+        # frame saturates, the others do not)
+        assert R.last_stats["n_visible"] == st["n_visible"]
+        if name == "960x540":
+            assert abs(R.last_stats["wave_entries"] - st["wave_entries"]) <= 0.005 * st["wave_entries"]
+        else:
+            assert R.last_stats["wave_entries"] == st["wave_entries"]
         assert torch.equal(R.render(cam, mk(fine_binning=True, **kw)), img)
     assert torch.equal(R.render(cam), coarse[0][0])
