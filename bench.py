@@ -7,7 +7,7 @@ A step = one complete 1920x1080 frame of the synthetic stand-in for MipNeRF-360 
 metric is quoted on (mip360_like(6_131_954, seed 361), ring camera 0) — in the reference's own
 arithmetic: fp32 coefficients, fp32 frame, reference_compat, every gaussian blended (no approximate early termination):
 preprocess -> depth sort -> tile binning -> blend, scene resident in HBM before the timed region — uploaded by the loader along a
-Morton curve of the gaussians' means (--scene-order; the `file_order` leg is the same frame from file-order arrays).  With N > 1 the SAME
+Morton curve of the gaussians' means (the loaders' default, --scene-order; the `file_order` leg is the same frame from file-order arrays).  With N > 1 the SAME
 frame is sharded by interleaved tile rows over the N GPUs and gathered to rank 0 over RCCL (strong scaling: total work
 per frame fixed).  `value` is throughput: --frames-in-flight independent frames (default 6) are in flight per GPU, each on
 its own HIP stream with its own workspace (renderer.FramesInFlight), every frame complete and bit-identical to
@@ -211,7 +211,16 @@ def stage_profile(R, scene, cam, opts, out_shape, tiles, reps, sh_half, prof, de
     stage = [float(np.mean([e[k].elapsed_time(e[k + 1]) for e in ev])) for k in range(3)]
     E, P, V = st["fetched_entries"], out.shape[0] * out.shape[1], st["n_visible"]  # E = entries actually fetched
     blend_bytes = 40.0 * E + 12.0 * P + 8.0 * tiles
-    pre_bytes = (140.0 if sh_half else 236.0) * n + 64.0 * V
+    # preprocess: 44 B of geometry per gaussian; the SH row (192 B, 96 B as fp16) and the outputs (48-B record + key + packed rect
+    # + the slack of the 64 B SURVEY.md §8(d) allows) only for the V visible ones — culled and off-screen gaussians never read
+    # their SH row (rounds 1-3 priced every gaussian at 236 B: a figure that could exceed the HBM peak)
+    pre_bytes = 44.0 * n + ((96.0 if sh_half else 192.0) + 64.0) * V
+    # bin + sort, as THIS design moves them: depth sort of the V visible keys (pass 0 reads all N keys twice —
+    # histogram, scatter — and writes V (key, id, packed rect) triples; each later pass reads V keys for its histogram, then reads
+    # and writes the V triples), pair count / emit (reads the V ids + rects, writes D (cell key, value) pairs), the 2-pass cell
+    # sort (per pass: D keys for the histogram, D pairs read and written), the range scan over the D sorted keys
+    D, passes = st["n_pairs_bbox"], max(1, st["sort_passes"])
+    sort_bytes = 8.0 * n + 12.0 * V + (passes - 1) * 28.0 * V + 12.0 * V + 8.0 * D + 2 * 20.0 * D + 4.0 * D + 8.0 * tiles
     achieved = blend_bytes / (stage[2] * 1e-3) / 1e9
     roof = {
         "kernel": "gsr::blend_walk_kernel", "bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -237,8 +246,48 @@ def stage_profile(R, scene, cam, opts, out_shape, tiles, reps, sh_half, prof, de
                                     "source": "tools/valu_microbench.hip on MI355X, 8 waves per SIMD (profiles/r3_valu_microbench.txt)"}
     if prof.get("lds_busy_frac") is not None:
         roof["lds_busy_frac_profiled"] = prof["lds_busy_frac"]
-    return {"roofline": roof, "stage_ms": {"preprocess": stage[0], "bin_sort": stage[1], "blend": stage[2]},
-            "stage_hbm_gbs": {"preprocess": pre_bytes / (stage[0] * 1e-3) / 1e9}, "stats": st}
+    copy_gbs = measured_copy_gbs(dev)
+
+    def stage_roof(kernel, bound, nbytes, ms, traffic, note):
+        a = nbytes / (ms * 1e-3) / 1e9
+        return {"kernel": kernel, "bound": bound, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_kernel_ms": ms,
+                "frac_of_measured_copy": a / copy_gbs if copy_gbs else None, "note": note}
+
+    stage_roofs = {
+        "preprocess": stage_roof("gsr::preprocess_kernel", "hbm", pre_bytes, stage[0], prof.get("preprocess_bytes_per_launch"),
+                                 "44 N + (192 + 64) V bytes: the SH row and the outputs only for visible gaussians"),
+        "bin_sort": stage_roof("gsr::radix_* + pair_* + tile_* (the stage's ~20 dispatches together)", "hbm", sort_bytes, stage[1],
+                               prof.get("bin_sort_bytes_per_frame"),
+                               "bytes as this design moves them (bench.py stage_profile); the stage is bound by the latency of its "
+                               "short dependent kernels, not by HBM"),
+    }
+    roof["hbm_copy_gbs_measured"] = copy_gbs
+    return {"roofline": roof, "stage_rooflines": stage_roofs, "hbm_copy_gbs_measured": copy_gbs,
+            "stage_ms": {"preprocess": stage[0], "bin_sort": stage[1], "blend": stage[2]}, "stats": st}
+
+
+_COPY_GBS = {}
+
+
+def measured_copy_gbs(dev):
+    """What a plain device-to-device copy of 1 GiB sustains on THIS GPU in THIS run (read + write bytes over the time of the best of
+    5): the practical ceiling of an HBM-bound kernel, printed beside the 8 TB/s spec the contract fractions are taken against."""
+    key = str(dev)
+    if key not in _COPY_GBS:
+        a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        b = torch.empty_like(a)
+        best = float("inf")
+        for _ in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            b.copy_(a)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        _COPY_GBS[key] = 2.0 * a.numel() * 4 / (best * 1e-3) / 1e9
+        del a, b
+    return _COPY_GBS[key]
 
 
 def main():
@@ -405,7 +454,9 @@ def main():
             "config": {"workload": f"{'real' if real else args.workload}: {desc}", "gaussians": n, "width": W, "height": H,
                        "camera": args.camera if ncam == 1 else f"cycling over {ncam} cameras",
                        "sharding": f"tile rows interleaved over {world} GPU(s), RCCL gather to rank 0" if world > 1 else "none",
-                       "scene_order": "morton curve of the means (loader option spatial_order; same frame up to exact depth ties)" if spatial else "file",
+                       "scene_order": ("morton curve of the means: the loaders' default (GaussianScene.sort_spatially, on the GPU at upload); "
+                                       "same frame up to exact depth ties") if spatial else "file (spatial_order=False)",
+                       "scene_order_ms_at_upload": scene.order_ms,
                        "reference_compat": True, "early_out_T": args.early_out_T, "depth_sort_passes": R.sort_passes, "sh_storage": "f16" if args.sh_half else "f32",
                        "frame_storage": "bf16 (fp32 accumulation)" if args.bf16_output else "f32",
                        "blend_impl": {0: "valu", 1: "valu, plain-C walk"}.get(args.blend_impl, str(args.blend_impl))},

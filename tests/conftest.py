@@ -48,3 +48,28 @@ def assert_frames_close(img, ref, min_db=100.0):
     assert psnr(img, ref) >= min_db, psnr(img, ref)
     assert (d > 1e-5).mean() <= 1e-4, (d > 1e-5).mean()
     assert d.max() <= 4.5e-3, d.max()
+
+
+INRIA_PROPERTIES = (["x", "y", "z", "nx", "ny", "nz"] + [f"f_dc_{i}" for i in range(3)] + [f"f_rest_{i}" for i in range(45)]
+                    + ["opacity"] + [f"scale_{i}" for i in range(3)] + [f"rot_{i}" for i in range(4)])
+
+
+def write_inria_ply(path, cols):
+    """A point_cloud.ply as the INRIA trainer writes it (gaussian-splatting scene/gaussian_model.py save_ply: 62 float
+    properties in this order — positions, the unused normals, f_dc, f_rest, opacity, scale, rot — binary_little_endian, one
+    `vertex` element, a plyfile-style header with a comment line), put together BYTE BY BYTE here: this file is not produced by
+    the package's own writer, so reading it pins the reader's name-based access with extra columns present
+    (reference rasterize.py:98-106,355,358; utils.py:21,27)."""
+    import struct
+
+    n = len(cols["x"])
+    head = "ply\nformat binary_little_endian 1.0\ncomment trained gaussians\nelement vertex %d\n" % n
+    head += "".join(f"property float {p}\n" for p in INRIA_PROPERTIES) + "end_header\n"
+    assert len(INRIA_PROPERTIES) == 62
+    rows = bytearray()
+    for i in range(n):
+        for p in INRIA_PROPERTIES:
+            rows += struct.pack("<f", float(cols[p][i]) if p in cols else 0.0)   # nx, ny, nz: zeros, like the trainer writes
+    with open(path, "wb") as f:
+        f.write(head.encode("ascii"))
+        f.write(bytes(rows))

@@ -271,3 +271,46 @@ def test_configs3_sharded_frame_over_rccl(G):
     p = _run_dist_check("nccl", ranks)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "DIST_CHECK_OK" in p.stdout
+
+
+def _run_bench_multi(backend, ranks, extra=(), timeout=900):
+    env = dict(os.environ)
+    env["GSR_BENCH_BACKEND"] = backend
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    port = 31500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(ranks), "--steps", "6", "--warmup", "2",
+           "--gaussians", "400000", "--legs", "", "--no-psnr", "--no-cpu-baseline", *extra]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _check_bench_line(p, ranks):
+    import json
+
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == ranks and r["scaling"] == "strong" and r["steps"] == 6 and r["warmup"] == 2
+    assert r["value"] > 0 and abs(r["value"] * r["ms_per_step"] - 1e3) < 1e-3 * 1e3
+    assert "tile rows interleaved" in r["config"]["sharding"] and str(ranks) in r["config"]["sharding"]
+    assert r["config"]["gaussians"] == 400000 and r["metric"].startswith("frames/sec @1080p")
+    assert r["roofline"]["frac"] > 0 and r["roofline"]["avg_kernel_ms"] > 0 and "rank 0's shard" in r["roofline"]["note"]
+    assert r["stats_rank0_shard"]["overflow"] == 0 and r["stats"]["overflow"] == 0 and r["stats"]["n_visible"] > 0
+    assert r["single_stream"]["frames_per_s"] > 0
+    return r
+
+
+def test_bench_py_with_two_ranks_over_gloo(G):
+    """The driver's multi-GPU command line — `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` — with N = 2
+    ranks sharing this box's GPU over gloo (GSR_BENCH_BACKEND), a small scene, no legs: the whole N > 1 half of bench.py
+    (sharded frames in flight, asynchronous gather, max-over-ranks timing, rank 0's roofline of its shard, every slot's counters
+    read after the timed loop) must run to ONE well-formed JSON line.  The first 8-GPU lease must not be spent on a traceback."""
+    r = _check_bench_line(_run_bench_multi("gloo", 2), 2)
+    print(f"\nbench.py --gpus 2 over gloo (ranks share the GPU): {r['value']:.0f} frames/s, {r['ms_per_step']:.3f} ms per frame")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs for RCCL")
+def test_bench_py_with_two_ranks_over_rccl(G):
+    r = _check_bench_line(_run_bench_multi("nccl", 2), 2)
+    print(f"\nbench.py --gpus 2 over RCCL: {r['value']:.0f} frames/s, {r['ms_per_step']:.3f} ms per frame")

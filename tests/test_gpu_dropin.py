@@ -131,6 +131,31 @@ def test_run_rasterization_cli_reproduces_the_reference_frame(mods, tmp_path):
         mods.rasterize.render_scene(scene_dir, model_dir, 0, 2)
 
 
+def test_run_rasterization_cli_on_an_inria_layout_model(mods, tmp_path):
+    """The same run with the model file laid out as the INRIA trainer writes it — 62 float properties with the unused normals, in
+    its order, the header and rows put together byte by byte by the test (conftest.write_inria_ply), NOT by the package's writer —
+    read by name through ply.PlyData.read like the reference reads through plyfile (rasterize.py:98-106,353-358; utils.py:21,27).
+    Real INRIA files and the `plyfile` library are not available here: this pins the layout, not real data."""
+    from click.testing import CliRunner
+
+    from conftest import write_inria_ply
+
+    g = load_golden("f2_small.npz")
+    scene_dir, model_dir = _write_scene(mods, str(tmp_path), g)
+    ply_path = os.path.join(model_dir, "point_cloud", "iteration_30000", "point_cloud.ply")
+    small = os.path.getsize(ply_path)
+    write_inria_ply(ply_path, golden_columns(g))
+    assert os.path.getsize(ply_path) > small                     # three more columns per gaussian
+    out_dir = str(tmp_path / "out")
+    res = CliRunner().invoke(mods.rasterize.run_rasterization, [
+        "--input_dir", scene_dir, "--trained_model_path", model_dir, "--output_path", out_dir,
+        "--scene-index", str(int(g["image_id"])), "--scale-factor", "2"], catch_exceptions=False)
+    assert res.exit_code == 0, res.output
+    img = np.load(os.path.join(out_dir, "render.npy"))
+    assert psnr(img, g["image"]) >= 100.0
+    assert_frames_close(img, g["image"])
+
+
 def test_run_rasterization_cli_scale_factor_4(mods, tmp_path):
     """BASELINE configs[0] as worded ("scale-factor 4") on fixture f3b: the reference's own run with --scale-factor 4 over
     images_4/ (image_id 42, a tilted camera, a 150x93 frame that is no multiple of 16).  Quirk Q3: the EWA focal stays

@@ -490,14 +490,18 @@ def test_depth_ties_resolve_by_index(G):
     for k in "xyz":
         cols[k] = np.ascontiguousarray(cols[k][np.arange(20_000) % 40])
     packed = G.utils.pack_gaussians(cols)
-    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(packed))
+    # (file order: ties resolve by SCENE index, and the oracle's scene is the file)
+    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(packed, spatial_order=False))
     img = R.render(cam).cpu().numpy()
     oimg, _ = G.orc.render(packed, ocam)
     assert R.last_stats["n_visible"] > 5_000
+    # the loaders' default order keeps gaussians at one POSITION in file order (equal ranks are consecutive on every axis, the
+    # curve is sorted stably): the same frame
+    assert torch.equal(G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(packed)).render(cam).cpu(), torch.from_numpy(img))
     assert_frames_close(img, oimg)
     # and it is the order, not luck: reversing the gaussians inside the ties changes the frame
     rev = {k: np.ascontiguousarray(v[::-1]) for k, v in cols.items()}
-    img_rev = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(rev)).render(cam).cpu().numpy()
+    img_rev = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(rev, spatial_order=False)).render(cam).cpu().numpy()
     assert np.abs(img_rev - img).max() > 1e-3
 
 
@@ -795,16 +799,21 @@ def test_f5_deep_stacks_against_the_reference_frame(G):
 
 
 def test_spatial_order_renders_the_same_frame(G):
-    """GaussianScene(spatial_order=True) uploads the arrays in Morton order of the means (renderer.morton_order: a permutation).
-    The reference's result does not depend on storage order — its depth sort orders the draw — except for gaussians at exactly
-    equal depth, so: same counters; the frame bit-identical when no two visible gaussians share a depth, and within the usual
-    tolerance of the oracle either way."""
+    """The loaders upload the arrays in Morton order of the means (GaussianScene.sort_spatially, on the device; the default since
+    round 4) — the same permutation as the numpy statement renderer.morton_order.  The reference's result does not depend on
+    storage order — its depth sort orders the draw — except for gaussians at exactly equal depth, so: same counters; the frame
+    bit-identical when no two visible gaussians share a depth, and within the usual tolerance of the oracle either way."""
     cols, cam, ocam = _medium(G, n=150_000)
     packed = G.utils.pack_gaussians(cols)
-    plain = G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(packed))
-    scene = G.renderer.GaussianScene.from_packed(packed, spatial_order=True)
+    plain_scene = G.renderer.GaussianScene.from_packed(packed, spatial_order=False)
+    assert plain_scene.order is None
+    plain = G.renderer.Rasterizer(plain_scene)
+    scene = G.renderer.GaussianScene.from_packed(packed)
     assert sorted(scene.order.tolist()) == list(range(150_000)) and not np.array_equal(scene.order, np.arange(150_000))
-    assert np.array_equal(scene.t["means"].cpu().numpy(), packed["means"][scene.order])
+    assert np.array_equal(scene.order, G.renderer.morton_order(packed["means"]))      # device sorts == the numpy statement
+    for k in scene.FIELDS:
+        assert np.array_equal(scene.t[k].cpu().numpy(), packed[k][scene.order]), k
+    assert scene.sort_spatially() is scene and scene.order_ms > 0
     R = G.renderer.Rasterizer(scene)
     a, b = plain.render(cam), R.render(cam)
     for k in ("n_visible", "n_pairs_bbox", "n_pairs"):
@@ -817,11 +826,10 @@ def test_spatial_order_renders_the_same_frame(G):
     assert float((a - b).abs().max()) < 1e-4 and psnr(b.cpu().numpy(), a.cpu().numpy()) >= 110.0, ties
     oimg, _ = G.orc.render(packed, ocam)
     assert_frames_close(b.cpu().numpy(), oimg)
-    # per-gaussian outputs are in scene order: order maps them back to file order
-    dbg = R.preprocess_debug(cam)["cam_means"].cpu().numpy()
-    back = np.empty_like(dbg)
-    back[scene.order] = dbg
-    assert np.array_equal(back[:, 2], z)
+    # per-gaussian outputs come back in FILE order whatever the scene's order
+    da, db = plain.preprocess_debug(cam), R.preprocess_debug(cam)
+    for k in da:
+        assert torch.equal(da[k], db[k]), k
 
 
 def test_a_fresh_workspace_needs_no_initialisation(G):

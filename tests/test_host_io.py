@@ -145,3 +145,36 @@ def test_morton_order_is_a_locality_preserving_permutation():
     step = lambda q: float(np.median(np.linalg.norm(np.diff(q, axis=0), axis=1)))
     assert step(r[p]) < 0.2 * step(r)
     assert np.array_equal(renderer.morton_order(m), p)          # deterministic
+    # the loaders' path (torch sorts on the device the means live on; here the CPU) builds the same permutation, also with
+    # repeated coordinates (stable sorts on both sides)
+    import torch
+    assert np.array_equal(renderer.morton_order_device(torch.from_numpy(m)).numpy(), p)
+    dup = np.ascontiguousarray(m[np.arange(len(m)) % 97])
+    assert np.array_equal(renderer.morton_order_device(torch.from_numpy(dup)).numpy(), renderer.morton_order(dup))
+    assert len(renderer.morton_order_device(torch.from_numpy(m[:0]))) == 0
+
+
+def test_inria_trained_model_header_is_read_by_name(tmp_path):
+    """The file layout of a real trained model (62 float properties incl. the unused normals, INRIA order), written byte by byte by
+    the test itself (conftest.write_inria_ply), not by ply.write_gaussians_ply: PlyData.read must find every column the reference
+    reads BY NAME (rasterize.py:98-106,355,358; utils.py:21,27) among the extras, and pack_gaussians must lay them out as
+    read_color_components does (sh[n,0,c] = f_dc_c, sh[n,k,c] = f_rest_{15c+k-1})."""
+    from conftest import INRIA_PROPERTIES, golden_columns, load_golden, write_inria_ply
+    from gsr_amd import ply, utils
+
+    cols = golden_columns(load_golden("f1_unit.npz"))
+    path = str(tmp_path / "point_cloud.ply")
+    write_inria_ply(path, cols)
+    assert os.path.getsize(path) == len(open(path, "rb").read().split(b"end_header\n")[0]) + len(b"end_header\n") + 62 * 4 * len(cols["x"])
+    el = ply.PlyData.read(path).elements[0]
+    assert el.name == "vertex" and el.properties == INRIA_PROPERTIES and len(el) == len(cols["x"])
+    for k, v in cols.items():
+        assert np.array_equal(el[k], v), k
+    for k in ("nx", "ny", "nz"):
+        assert not el[k].any()
+    a, b = utils.pack_gaussians(el), utils.pack_gaussians(cols)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert a["sh"].shape == (len(cols["x"]), 16, 3) and np.array_equal(a["sh"][:, 0, 1], cols["f_dc_1"]) and np.array_equal(a["sh"][:, 3, 2], cols["f_rest_32"])
+    got = ply.read_gaussians_columns(path)
+    assert set(got) == set(INRIA_PROPERTIES) and all(v.dtype == np.float32 and v.flags["C_CONTIGUOUS"] for v in got.values())

@@ -29,11 +29,18 @@ def main():
                          os.path.join(src, "trace_kernel_trace.csv"), "+20"], capture_output=True, text=True).stdout  # a frame of the timed loop
     open(out + "_frame_timeline.txt", "w").write(tl)
     pmc = {}
+    stage_sum = collections.defaultdict(float)  # (stage, counter) -> total over every launch of the run
+    frames = {}
+    BIN_SORT = ("radix_hist", "radix_rowscan", "radix_scatter", "pair_count", "pair_scan", "pair_emit", "tile_ranges", "tile_order", "shard_compact")
     for f in sorted(glob.glob(os.path.join(src, "pmc_*_counter_collection.csv"))):
         per = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             kern = "blend_kernel" if ("blend_walk_kernel" in r["Kernel_Name"] or "blend_kernel" in r["Kernel_Name"]) else ("preprocess_kernel" if "preprocess_kernel" in r["Kernel_Name"] else r["Kernel_Name"][:40])
             per[kern][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if any(k in r["Kernel_Name"] for k in BIN_SORT):
+                stage_sum[("bin_sort", r["Counter_Name"])] += float(r["Counter_Value"])
+        for c, v in per.get("blend_kernel", {}).items():
+            frames[c] = len(v)  # one blend launch per frame
         for kern, cs in per.items():
             for c, v in cs.items():
                 steady = v[len(v) // 2:]  # drop warm-up launches
@@ -77,6 +84,13 @@ def main():
                 t["salu_issue_frac"] = c["SQ_INSTS_SALU"] / 256.0 / cyc  # one scalar unit per CU
             if "SQ_INSTS_VALU" in c:
                 t["valu_issue_frac_2cyc"] = c["SQ_INSTS_VALU"] * 2.0 / 1024.0 / cyc  # at the 2-cycle floor of a wave64 VALU op
+    # per-stage HBM traffic for bench.py's stage_rooflines: the preprocess kernel per launch, the bin + sort stage per frame (all its
+    # dispatches together; FETCH_SIZE x2 + WRITE_SIZE like the blend's)
+    t = traffic.setdefault(workload, {})
+    if "preprocess_kernel" in derived and "hbm_bytes_per_launch" in derived["preprocess_kernel"]:
+        t["preprocess_bytes_per_launch"] = derived["preprocess_kernel"]["hbm_bytes_per_launch"]
+    if ("bin_sort", "FETCH_SIZE") in stage_sum and ("bin_sort", "WRITE_SIZE") in stage_sum and frames.get("FETCH_SIZE") and frames.get("WRITE_SIZE"):
+        t["bin_sort_bytes_per_frame"] = (2 * stage_sum[("bin_sort", "FETCH_SIZE")] / frames["FETCH_SIZE"] + stage_sum[("bin_sort", "WRITE_SIZE")] / frames["WRITE_SIZE"]) * 1024
     json.dump(traffic, open(tfile, "w"), indent=1)
     print(tl)
     print(json.dumps(derived, indent=1))

@@ -52,20 +52,51 @@ def morton_order(means: np.ndarray) -> np.ndarray:
     return np.argsort(code, kind="stable")
 
 
+def morton_order_device(means: torch.Tensor) -> torch.Tensor:
+    """morton_order on the device the means live on (the loaders' path: ~5 s of numpy for 6 M gaussians became a few sorts on the
+    GPU at upload, off the render path): the same permutation, element for element — per axis a stable argsort and its inverse give
+    the ranks, the quantised ranks are interleaved into 30-bit codes, one more stable argsort orders them."""
+    n = int(means.shape[0])
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int64, device=means.device)
+
+    def spread(v):  # 10 bits -> every third bit
+        v = v & 0x3FF
+        v = (v | (v << 16)) & 0x30000FF
+        v = (v | (v << 8)) & 0x300F00F
+        v = (v | (v << 4)) & 0x30C30C3
+        v = (v | (v << 2)) & 0x9249249
+        return v
+
+    ar = torch.arange(n, dtype=torch.int64, device=means.device)
+    code = torch.zeros(n, dtype=torch.int64, device=means.device)
+    for a in range(3):
+        idx = torch.argsort(means[:, a].float(), stable=True)
+        rank = torch.empty_like(idx)
+        rank[idx] = ar
+        code |= spread(rank * 1024 // n) << a
+    return torch.argsort(code, stable=True)
+
+
 class GaussianScene:
     """Camera-independent trained gaussians, resident in HBM in the layout of GsrScene.
 
-    `spatial_order=True` (loaders below) uploads the arrays in Morton order of the means instead of file order (`order` then
-    holds the permutation: scene index -> file index).  The frame is the same — the reference's depth sort does not depend on
-    storage order, except for gaussians at EXACTLY equal depth, whose mutual order the reference leaves undefined and this
-    library resolves by scene index — and it renders ~5 % faster (bench.py's `spatial_order` leg).  Per-gaussian
-    outputs (`Rasterizer.preprocess_debug`) are in scene order."""
+    The loaders below upload the arrays along a Morton curve of the means (`spatial_order=True`, their default since round 4;
+    `order` holds the permutation: scene index -> file index, None in file order).  A trained .ply is in no spatial order while a
+    camera sees a spatial region: in curve order the preprocess culls whole waves, the SH rows of the visible gaussians are
+    contiguous and the blend's record gathers hit L2 more often — ~10 % of the frame (bench.py's `file_order` leg).
+    The frame is the same: the reference's depth sort orders the draw, not the storage order — except for gaussians at EXACTLY
+    equal depth, whose mutual order the reference leaves undefined (torch.sort, rasterize.py:425, is unstable) and this library
+    resolves by scene index.  Per-gaussian outputs (`Rasterizer.preprocess_debug`) come back in FILE order either way.
+    The constructor takes device arrays as they are (no reordering): that is the C ABI's view."""
 
     FIELDS = ("means", "log_scales", "quats", "opacity_logit", "sh")
 
     def __init__(self, arrays: Mapping[str, torch.Tensor], sh_degree: int = 3, sh_half: bool = False):
         self.t: Dict[str, torch.Tensor] = {}
-        self.order: Optional[np.ndarray] = None
+        self.order_t: Optional[torch.Tensor] = None  # device, int64: scene index -> file index (None: file order)
+        self._order_np: Optional[np.ndarray] = None
+        self.order_ms = 0.0                          # what building the order and gathering the arrays cost at upload
         self.sh_half = bool(sh_half)
         for k in self.FIELDS:
             v = arrays[k]
@@ -80,23 +111,44 @@ class GaussianScene:
             if tuple(self.t[k].shape) != shp:
                 raise ValueError(f"{k}: expected shape {shp}, got {tuple(self.t[k].shape)}")
 
+    @property
+    def order(self) -> Optional[np.ndarray]:
+        """scene index -> file index as a numpy array (None: the scene is in file order)."""
+        if self.order_t is None:
+            return None
+        if self._order_np is None:
+            self._order_np = self.order_t.cpu().numpy()
+        return self._order_np
+
+    def sort_spatially(self) -> "GaussianScene":
+        """Reorder the resident arrays along the Morton curve of the means (on the device; a scene already ordered is left alone)."""
+        if self.order_t is not None or self.n == 0:
+            return self
+        t0 = torch.cuda.Event(enable_timing=True)
+        t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        order = morton_order_device(self.t["means"])
+        for k in self.FIELDS:
+            self.t[k] = self.t[k].index_select(0, order).contiguous()
+        t1.record()
+        t1.synchronize()
+        self.order_t, self._order_np, self.order_ms = order, None, float(t0.elapsed_time(t1))
+        return self
+
     @classmethod
-    def from_columns(cls, columns, device="cuda", sh_degree: int = 3, sh_half: bool = False, spatial_order: bool = False) -> "GaussianScene":
+    def from_columns(cls, columns, device="cuda", sh_degree: int = 3, sh_half: bool = False, spatial_order: bool = True) -> "GaussianScene":
         """`columns`: ply element / dict of float32 columns named as in the INRIA .ply."""
         return cls.from_packed(pack_gaussians(columns), device, sh_degree, sh_half, spatial_order)
 
     @classmethod
     def from_packed(cls, packed: Mapping[str, np.ndarray], device="cuda", sh_degree: int = 3, sh_half: bool = False,
-                    spatial_order: bool = False) -> "GaussianScene":
-        order = morton_order(np.asarray(packed["means"], np.float32)) if spatial_order else None
-        pick = (lambda a: a) if order is None else (lambda a: a[order])
-        scene = cls({k: torch.from_numpy(np.ascontiguousarray(pick(np.asarray(packed[k], np.float32)))).to(device) for k in cls.FIELDS},
+                    spatial_order: bool = True) -> "GaussianScene":
+        scene = cls({k: torch.from_numpy(np.ascontiguousarray(np.asarray(packed[k], np.float32))).to(device) for k in cls.FIELDS},
                     sh_degree, sh_half)
-        scene.order = order
-        return scene
+        return scene.sort_spatially() if spatial_order else scene
 
     @classmethod
-    def from_ply(cls, path: str, device="cuda", sh_degree: int = 3, sh_half: bool = False, spatial_order: bool = False) -> "GaussianScene":
+    def from_ply(cls, path: str, device="cuda", sh_degree: int = 3, sh_half: bool = False, spatial_order: bool = True) -> "GaussianScene":
         from .ply import PlyData
 
         return cls.from_columns(PlyData.read(path), device, sh_degree, sh_half, spatial_order)
@@ -334,7 +386,8 @@ class Rasterizer:
 
     # -- stage-by-stage (tests, helper functions) -------------------------------------------------
     def preprocess_debug(self, cam: GsrCamera, opts: Optional[GsrOptions] = None) -> Dict[str, torch.Tensor]:
-        """Run stage 1 alone and return every per-gaussian intermediate the reference's helpers produce."""
+        """Run stage 1 alone and return every per-gaussian intermediate the reference's helpers produce, indexed like the
+        file the scene was loaded from (whatever order the scene is stored in)."""
         opts = opts or make_options()
         n, dev = self.scene.n, self.scene.device
         f32, i64 = torch.float32, torch.int64
@@ -352,6 +405,11 @@ class Rasterizer:
         sc = self.scene.c_struct()
         check(lib.gsr_preprocess(C.byref(sc), C.byref(cam), C.byref(opts), ws.data_ptr(), ws.numel(), C.byref(dbg),
                                  _stream_ptr(dev)))
+        if self.scene.order_t is not None:  # the library works in scene order; callers (and the reference's helpers) index by file order
+            for k, v in out.items():
+                back = torch.empty_like(v)
+                back[self.scene.order_t] = v
+                out[k] = back
         return out
 
 
