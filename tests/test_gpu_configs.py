@@ -129,7 +129,12 @@ def box4k(G):
     p = G.synthetic.box_camera()
     fx = G.synthetic.pinhole_focal(W)
     args = (p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H)
-    scene = G.renderer.GaussianScene.from_packed(packed)
+    scene = G.renderer.GaussianScene.from_packed(packed)          # the loaders' default: along the Morton curve
+    # The camera looks down +z from (0, 0, -14): depth = z + 14, and 20 M fp32 draws from U[-10, 10] repeat values — thousands of
+    # EXACT depth ties, whose order the reference leaves undefined (torch.sort is unstable) and this library resolves by scene index.
+    # The oracle resolves them by ITS index, so it is fed the arrays in the scene's order: same gaussians, same tie order.
+    order = scene.order
+    packed = {k: np.ascontiguousarray(v[order]) for k, v in packed.items()}
     return packed, scene, G.renderer.make_camera(*args), G.orc.camera(*args)
 
 
