@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--workload", default="bicycle", choices=sorted(WORKLOADS))
     ap.add_argument("--gaussians", type=int, default=0, help="override the gaussian count (0 = the workload's)")
     ap.add_argument("--early-out-T", type=float, default=0.0)
+    ap.add_argument("--colour-stage", type=int, default=0, help="GsrOptions.colour_stage: 0 = sh_to_rgb in the blend's staging (default), 1 = in the preprocess")
     ap.add_argument("--blend-impl", type=int, default=0, help="0 default blend, 1 the same with its walk in plain C")
     ap.add_argument("--sh-half", action="store_true", help="headline with SH coefficients stored as fp16 (default: fp32, the reference's type)")
     ap.add_argument("--bf16-output", action="store_true", help="headline with the frame stored as bfloat16; accumulation stays fp32")
@@ -339,7 +340,7 @@ def main():
     R = fif.rasterizers[0]
     state = {"i": 0}
     if world == 1:  # no sharding: blend straight into a frame buffer per slot
-        opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl, output_bf16=args.bf16_output)
+        opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl, output_bf16=args.bf16_output, colour_stage=args.colour_stage)
         frames = [torch.zeros((H, W, 3), dtype=out_dtype, device=dev) for _ in range(S)]
         strip_view = frames[0]
 
@@ -353,7 +354,7 @@ def main():
             return None
     else:
         opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl, output_bf16=args.bf16_output,
-                                     **plan.shard_options(rank))
+                                     colour_stage=args.colour_stage, **plan.shard_options(rank))
         # gdist.ShardedFrames: frame f renders on stream f % S into wire buffer f % S, its strip is gathered asynchronously
         # over RCCL while the next frames render, frames are finished in order on the main stream
         sf = gdist.ShardedFrames(plan, rank, dev, S, lambda k, c, strip: fif.rasterizers[k].enqueue(c, opts, out=strip),
@@ -471,7 +472,7 @@ def main():
     if rank == 0:
         if world == 1:
             frame = R.enqueue(cam, opts, out=strip_view)  # the frame checked against the oracle below is camera 0's
-        full_opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl, depth_sort_passes=R.sort_passes,
+        full_opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl, depth_sort_passes=R.sort_passes, colour_stage=args.colour_stage,
                                           **(plan.shard_options(rank) if world > 1 else {}))
         prof = stage_profile(R, scene, cam, full_opts, plan.strip_shape(rank) if world > 1 else (H, W, 3),
                              len(plan.rows[rank]) * ((W + 15) // 16) if world > 1 else ((W + 15) // 16) * ((H + 15) // 16),

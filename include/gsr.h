@@ -131,6 +131,15 @@ typedef struct GsrOptions {
                                  whole-frame kernel, 2 = always the three-phase kernel (csrc/preprocess.hip).  Was GSR_SHARD_PREPROCESS. */
     int32_t blend_pipe_tiles; /* tile count up to which the blend runs its pipelined one-quadrant walk: 0 (default) = 1280, -1 = never
                                  (csrc/blend.hip).  Was GSR_BLEND_PIPE_TILES. */
+    int32_t colour_stage;     /* where is sh_to_rgb (spherical_harmonics.py:27-73) evaluated?
+                                 0 (default): in the blend, when a tile first STAGES a gaussian (its 192-B SH row is read and its colour
+                                 evaluated then, and remembered in the gaussian's record for the tiles that stage it later): gaussians
+                                 that no tile reaches before it is saturated — most of a dense scene — never read their SH row.  The
+                                 preprocess then reads 44 B per gaussian instead of up to 236.  Same arithmetic in the same order on the
+                                 same inputs: frames are bit-identical to 1.
+                                 1: in gsr_preprocess, for every visible gaussian (rounds 1-3) — the A/B reference of 0.
+                                 (gsr_preprocess with a GsrDebugOut always evaluates there: `rgb` is one of its outputs.)  Only
+                                 gsr_preprocess reads this field; gsr_blend finds out from the records. */
     int32_t sh_dense_min;     /* visible gaussians per wave from which the preprocess fetches the wave's 64 SH rows whole through LDS:
                                  0 (default) = 48, 65 = never (csrc/preprocess.hip).  Was GSR_SH_DENSE. */
 } GsrOptions;
@@ -148,6 +157,9 @@ typedef struct GsrStats {
                                overflow bit 1 is set: the most any frame since the last cleared one (keep_flags, batches) needed */
     uint64_t wave_entries;  /* (8x8 quadrant, entry) pairs the blend actually evaluated: 64 pixel evaluations each */
     uint64_t fetched_entries; /* list entries the blend staged (<= n_pairs: a saturated tile stops fetching) */
+    uint64_t colour_evals;  /* sh_to_rgb evaluations (192-B SH rows read) by the blend: colour_stage = 0 evaluates a gaussian when a tile
+                               first stages it; tiles racing for the same gaussian may each evaluate it (same result).  0 when the
+                               preprocess evaluated the colours (colour_stage = 1: n_visible evaluations there). */
 } GsrStats;
 
 /* Optional intermediates of gsr_preprocess, one entry per gaussian, any pointer may be NULL.

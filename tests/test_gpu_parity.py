@@ -368,6 +368,33 @@ def test_colour_saturation_rule_is_exact(G):
     assert any(n0 < n1 for _, _, n1, n0 in saved)
 
 
+def test_deferred_colour_is_exact(G):
+    """GsrOptions.colour_stage = 0 (default): sh_to_rgb is evaluated when a tile first stages a gaussian (blend.hip, staged_q2) and
+    remembered in its record; 1: for every visible gaussian in the preprocess (rounds 1-3).  Same code (gauss_math.h sh_eval_with),
+    same operation order, contraction off in both translation units: frames must be bit-identical — every blend kernel variant,
+    shards (whole-frame and three-phase preprocess), SH degrees 0-3, fp16 SH storage, the T output, batches."""
+    mk = G.renderer.make_options
+    for name, cols, cam in _rule_cases(G):
+        packed = cols if "means" in cols else G.utils.pack_gaussians(cols)
+        for sh_kw in (dict(), dict(sh_degree=0), dict(sh_degree=2), dict(sh_half=True)):
+            if sh_kw and name not in ("medium 640x360", "960x540", "f2_small.npz"):
+                continue
+            R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(packed, **sh_kw))
+            for kw in (dict(), dict(blend_impl=1), dict(tile_row_begin=2, tile_row_step=5, output_layout=2), dict(tile_row_begin=1, tile_row_step=2, output_layout=2),
+                       dict(saturation_rule=1), dict(fine_binning=True), dict(draw_limit=997), dict(blend_pipe_tiles=-1), dict(accum_bf16=True)):
+                a, Ta = R.render(cam, mk(colour_stage=1, **kw), return_T=True)
+                assert R.last_stats["colour_evals"] == 0, (name, sh_kw, kw)
+                b, Tb = R.render(cam, mk(**kw), return_T=True)
+                assert torch.equal(a, b) and torch.equal(Ta, Tb), (name, sh_kw, kw)
+                # a gaussian is evaluated when a tile first stages it: at most once per staged entry, at least once if anything was staged
+                assert 0 < R.last_stats["colour_evals"] <= R.last_stats["fetched_entries"] or R.last_stats["fetched_entries"] == 0, (name, sh_kw, kw)
+                assert torch.equal(R.render(cam, mk(**kw)), R.render(cam, mk(colour_stage=1, **kw))), (name, sh_kw, kw)
+    cols, cam, _ = _medium(G, n=60_000)
+    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
+    cams = [cam, _medium(G, n=10, pose=5)[1], _medium(G, n=10, pose=11)[1]]
+    assert torch.equal(R.render_batch(cams), R.render_batch(cams, mk(colour_stage=1)))
+
+
 def test_early_out_is_a_bounded_approximation(G):
     cols, cam, _ = _medium(G)
     R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))

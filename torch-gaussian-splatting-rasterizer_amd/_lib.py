@@ -86,6 +86,7 @@ class GsrOptions(C.Structure):
         ("fine_binning", C.c_int32),
         ("shard_preprocess", C.c_int32),
         ("blend_pipe_tiles", C.c_int32),
+        ("colour_stage", C.c_int32),
         ("sh_dense_min", C.c_int32),
     ]
 
@@ -100,6 +101,7 @@ class GsrStats(C.Structure):
         ("sort_passes", C.c_uint32),
         ("wave_entries", C.c_uint64),
         ("fetched_entries", C.c_uint64),
+        ("colour_evals", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -92,6 +92,7 @@ static int check_frame(int64_t n, const GsrCamera *cam, const GsrOptions *opts, 
     if (opts->fine_binning != 0 && opts->fine_binning != 1) { set_error("bad fine_binning %d", opts->fine_binning); return GSR_ERR_BAD_ARG; }
     if (opts->shard_preprocess < 0 || opts->shard_preprocess > 2) { set_error("bad shard_preprocess %d", opts->shard_preprocess); return GSR_ERR_BAD_ARG; }
     if (opts->blend_pipe_tiles < -1) { set_error("bad blend_pipe_tiles %d", opts->blend_pipe_tiles); return GSR_ERR_BAD_ARG; }
+    if (opts->colour_stage != 0 && opts->colour_stage != 1) { set_error("bad colour_stage %d", opts->colour_stage); return GSR_ERR_BAD_ARG; }
     if (opts->sh_dense_min < 0 || opts->sh_dense_min > 65) { set_error("bad sh_dense_min %d", opts->sh_dense_min); return GSR_ERR_BAD_ARG; }
     if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) { set_error("workspace must be 256-byte aligned"); return GSR_ERR_BAD_ARG; }
     const size_t need = carve_workspace(workspace, n, cam->width, cam->height, max_pairs, ws);
@@ -340,7 +341,7 @@ int gsr_render_batch_slots(const GsrScene *scene, const GsrCamera *cams, int32_t
 int gsr_read_stats(void *workspace, size_t workspace_bytes, GsrStats *out, void *stream)
 {
     if (!workspace || !out || workspace_bytes < sizeof(FrameCtrl)) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
-    static_assert(sizeof(GsrStats) == 40 && offsetof(FrameCtrl, digit_tot) == sizeof(GsrStats), "GsrStats is the head of FrameCtrl");
+    static_assert(sizeof(GsrStats) == 48 && offsetof(FrameCtrl, digit_tot) == sizeof(GsrStats), "GsrStats is the head of FrameCtrl");
     hipStream_t s = static_cast<hipStream_t>(stream);
     {  // total the blend's per-workgroup counters; the kernel finds them through the offsets kept in FrameCtrl
         const int rc = launch_blend_stats(static_cast<FrameCtrl *>(workspace), workspace_bytes, s);

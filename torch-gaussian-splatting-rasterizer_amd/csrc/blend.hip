@@ -33,8 +33,63 @@
 #include "gsr_internal.h"
 #include "blend_args.h"
 #include "footprint.h"
+#include "gauss_math.h"
 
 namespace gsr {
+
+// A load through a pointer that came out of memory: say that it points to global memory, or the access is a flat_load.
+template <typename T>
+__device__ __forceinline__ T ldg(const T *p, size_t i)
+{
+    return ((const __attribute__((address_space(1))) T *)p)[i];
+}
+
+// q2 = {log2(opacity), r, g, b} of gaussian `id` for the staging thread.  With GsrOptions.colour_stage = 0 the preprocess leaves
+// the colour unevaluated (rgb negative; a colour is clamped to [0, 1], Q7): the first tile that STAGES the gaussian reads its mean
+// and its SH row, evaluates sh_to_rgb (spherical_harmonics.py:27-73; gauss_math.h sh_eval, the same code the preprocess runs, same
+// operation order, contraction off) and writes the result back into the record for the tiles that stage it later.  Gaussians no
+// tile reaches before it is saturated never read their 192-B row — on the bench frame the blend stages 3.0 M of 15.2 M list
+// entries.  Races are benign by construction: every writer stores the same three values, and a reader accepts the record's
+// colour only when all three channels are non-negative — whatever mix of old and new words it sees (another XCD's L2 may still
+// hold the line from before), it either uses the final values or evaluates them itself.
+__device__ __forceinline__ float4 staged_q2(const BlendArgs &a, uint32_t id, uint32_t &evals)
+{
+    GaussRec *r = a.rec + id;
+    float4 q2 = r->q2;
+    if (!(q2.y >= 0.0f && q2.z >= 0.0f && q2.w >= 0.0f)) {
+        const FrameCtrl *c = a.ctrl;
+        const float cc[3] = {c->col_cc[0], c->col_cc[1], c->col_cc[2]};
+        const float p[3] = {ldg(c->col_means, 3 * (size_t)id), ldg(c->col_means, 3 * (size_t)id + 1), ldg(c->col_means, 3 * (size_t)id + 2)};
+        float rgb[3];
+        // The evaluation consumes the row in memory order (sh_eval_with) and each element is loaded where it is consumed (the compiler
+        // merges them into 16-B loads, one in flight at a time): this runs inside a 64-VGPR kernel whose accumulators stay live, and
+        // what it costs is the bytes, not the round trips.  Measured on the bench frame (blend kernel, same box): 0.179 ms with the
+        // colours already in the records; this 0.234 ms for 1.80 M evaluations; groups of three 16-B pieces, two groups in flight
+        // (172 B of scratch per thread) 0.238; the whole row requested at once (spills) 0.327; without the write-back 0.281 ms for
+        // 3.00 M evaluations — ~31 ns per 1000 evaluations in every variant, the rate at which the preprocess read the rows it
+        // needed (650 MB in 0.11 ms): the saving is the rows never read.  The degree is a constant per branch (the reference
+        // always evaluates 3, rasterize.py:368).
+        const int degree = c->col_degree;
+        if (c->col_sh16) {
+            const unsigned *row = reinterpret_cast<const unsigned *>(static_cast<const char *>(c->col_sh) + 96 * (size_t)id);
+            auto get = [row](int e) {
+                const unsigned w = ldg(row, (size_t)(e >> 1));
+                return __half2float(__ushort_as_half((unsigned short)((e & 1) ? w >> 16 : w & 0xFFFFu)));
+            };
+            if (degree == 3) sh_eval_with(p, get, cc, 3, rgb);
+            else sh_eval_with(p, get, cc, degree, rgb);
+        } else {
+            const float *row = static_cast<const float *>(c->col_sh) + 48 * (size_t)id;
+            auto get = [row](int e) { return ldg(row, e); };
+            if (degree == 3) sh_eval_with(p, get, cc, 3, rgb);
+            else sh_eval_with(p, get, cc, degree, rgb);
+        }
+        q2.y = rgb[0]; q2.z = rgb[1]; q2.w = rgb[2];
+        r->q2 = q2;
+        ++evals;
+    }
+    return q2;
+}
 
 
 // one (pixel, entry) evaluation; g = {mean_x, mean_y}, c = {A, B, C, -}, o = {log2(opacity), r, g, b}.
@@ -816,6 +871,16 @@ __device__ __forceinline__ int tile_list_next(const BlendArgs &a, TileList<THREA
     return nb;
 }
 
+// stat[5] = the workgroup's deferred-colour evaluations: wave totals into LDS, one store.  Called once, at the end, by every thread.
+__device__ __forceinline__ void stat_colour_evals(uint32_t mine, uint32_t *s_col, uint32_t *stat)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += (uint32_t)__shfl_xor((int)mine, d, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(s_col, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) stat[5] = *s_col;
+}
+
 // Tile launch order.  Group g = tile rows g, g+8, ... of the shard (one XCD's share).  One workgroup per
 // group bucket-sorts its tiles by list length, longest first (buckets = exponent + 3 mantissa bits of the
 // length, i.e. within 12.5 %): order[8*j + g] = j-th tile of group g.  Slots past the end of a group hold -1.
@@ -879,13 +944,14 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
     __shared__ float4 srec[3][256];  // staged records, one plane per 16-B part: q0 at +0, q1 at +4096, q2 at +8192 bytes
     float4 *const s0 = srec[0], *const s1 = srec[1], *const s2 = srec[2];
     __shared__ int s_done;
+    __shared__ uint32_t s_col;
     __shared__ uint32_t s_ring[TileList<256>::RING], s_wc[2 * TileList<256>::WAVES];
 
     const int tile = a.order[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t *stat = a.stats + (size_t)blockIdx.x * BLEND_STAT_WORDS;
     if (tile < 0) {  // uniform: empty launch slot
-        if (tid < 5) stat[tid] = 0;
+        if (tid < 6) stat[tid] = 0;
         return;
     }
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
@@ -901,7 +967,8 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
     bool wave_done = false;
     uint32_t evaluated = 0;  // wave-uniform
     uint32_t fetched = 0;    // workgroup-uniform
-    if (tid == 0) s_done = 0;
+    uint32_t col_evals = 0;  // per thread: deferred colours this thread evaluated while staging
+    if (tid == 0) { s_done = 0; s_col = 0; }
 
     for (;;) {
         __syncthreads();  // previous batch fully consumed (and s_done initialised); a refilled ring published
@@ -915,7 +982,7 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
             const GaussRec *r = a.rec + id;
             s0[tid] = r->q0;
             s1[tid] = r->q1;
-            s2[tid] = r->q2;
+            s2[tid] = staged_q2(a, id, col_evals);
         }
         __syncthreads();
         if (wave_done) continue;
@@ -958,6 +1025,7 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
 
     if (lane == 0) stat[wave] = evaluated;
     if (tid == 0) stat[4] = fetched;
+    stat_colour_evals(col_evals, &s_col, stat);
     if (px < a.W && py < a.H) {
         const bool drawn = px < a.xlim && py < a.ylim;  // Q1: last column / row stay black, T stays 1
         const float r = drawn ? Cr : 0.0f, g = drawn ? Cg : 0.0f, b = drawn ? Cb : 0.0f;
@@ -991,6 +1059,7 @@ __global__ __launch_bounds__(256 / QPW, PIPE ? 5 : 8) void blend_walk_kernel(Ble
     float4 *const s0 = srec[0], *const s1 = srec[1], *const s2 = srec[2];
     const unsigned lds_rec = (unsigned)(size_t)&srec[0][0];  // LDS byte address: the low half of the flat pointer
     __shared__ int s_done;
+    __shared__ uint32_t s_col;
     __shared__ uint32_t s_ring[TileList<THREADS>::RING], s_wc[2 * WAVES];
 
     const int tile = a.order[blockIdx.x];
@@ -1000,7 +1069,7 @@ __global__ __launch_bounds__(256 / QPW, PIPE ? 5 : 8) void blend_walk_kernel(Ble
     const unsigned long long ts0 = wall_clock64();
 #endif
     if (tile < 0) {  // uniform: empty launch slot
-        if (tid < 5) stat[tid] = 0;
+        if (tid < 6) stat[tid] = 0;
         return;
     }
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
@@ -1019,7 +1088,8 @@ __global__ __launch_bounds__(256 / QPW, PIPE ? 5 : 8) void blend_walk_kernel(Ble
     const bool undrawnB = a.sat_scale != 0.0f && !(px + 8 < a.xlim && py < a.ylim);
     uint32_t evaluated = 0;                // wave-uniform
     uint32_t fetched = 0;                  // workgroup-uniform
-    if (tid == 0) s_done = 0;
+    uint32_t col_evals = 0;                // per thread: deferred colours this thread evaluated while staging
+    if (tid == 0) { s_done = 0; s_col = 0; }
 
     for (;;) {
         __syncthreads();  // previous batch fully consumed (and s_done initialised); a refilled ring published
@@ -1033,7 +1103,7 @@ __global__ __launch_bounds__(256 / QPW, PIPE ? 5 : 8) void blend_walk_kernel(Ble
             const GaussRec *r = a.rec + id;
             s0[tid] = r->q0;
             s1[tid] = r->q1;
-            s2[tid] = r->q2;
+            s2[tid] = staged_q2(a, id, col_evals);
         }
         __syncthreads();
         if (doneA && doneB) continue;
@@ -1072,7 +1142,8 @@ __global__ __launch_bounds__(256 / QPW, PIPE ? 5 : 8) void blend_walk_kernel(Ble
         if (QPW == 2) stat[2 + wave] = 0;
     }
     if (tid == 0) stat[4] = fetched;
-#ifdef GSR_BLEND_TIMESTAMPS
+    stat_colour_evals(col_evals, &s_col, stat);
+#ifdef GSR_BLEND_TIMESTAMPS  // (the timestamp build reuses stat[5])
     __syncthreads();
     if (tid == 0) {
         stat[5] = (uint32_t)ts0;
@@ -1112,6 +1183,7 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     a.cell_lists = blend_reads_cell_lists(ws, opts) ? 1 : 0;
     a.pval = lists;
     a.rec = ws.rec;
+    a.ctrl = ws.ctrl;
     a.out = out_image;
     a.out_T = out_T;
     a.stats = ws.blend_stats;
@@ -1149,29 +1221,32 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
 // the layout comes from FrameCtrl itself because gsr_read_stats is handed nothing but the workspace.
 __global__ __launch_bounds__(1024) void blend_stats_kernel(FrameCtrl *ctrl, size_t workspace_bytes)
 {
-    __shared__ unsigned long long part[2][16];
+    __shared__ unsigned long long part[3][16];
     const uint32_t off = ctrl->stats_off, slots = ctrl->stats_slots;
-    unsigned long long ev = 0, fe = 0;
+    unsigned long long ev = 0, fe = 0, ce = 0;
     if (off >= sizeof(FrameCtrl) && (size_t)off + (size_t)slots * BLEND_STAT_WORDS * 4 <= workspace_bytes) {
         const uint32_t *st = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(ctrl) + off);
         for (uint32_t i = threadIdx.x; i < slots; i += 1024) {
             const uint4 v = *reinterpret_cast<const uint4 *>(st + (size_t)i * BLEND_STAT_WORDS);
             ev += (unsigned long long)v.x + v.y + v.z + v.w;
             fe += st[(size_t)i * BLEND_STAT_WORDS + 4];
+            ce += st[(size_t)i * BLEND_STAT_WORDS + 5];
         }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         ev += __shfl_xor(ev, d, 64);
         fe += __shfl_xor(fe, d, 64);
+        ce += __shfl_xor(ce, d, 64);
     }
-    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = ev; part[1][threadIdx.x >> 6] = fe; }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = ev; part[1][threadIdx.x >> 6] = fe; part[2][threadIdx.x >> 6] = ce; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        ev = fe = 0;
-        for (int w = 0; w < 16; ++w) { ev += part[0][w]; fe += part[1][w]; }
+        ev = fe = ce = 0;
+        for (int w = 0; w < 16; ++w) { ev += part[0][w]; fe += part[1][w]; ce += part[2][w]; }
         ctrl->wave_entries = ev;
         ctrl->fetched_entries = fe;
+        ctrl->colour_evals = ce;
     }
     // E, when the blend reads the cell lists directly (binning.hip): the emit workgroups' partial counts, one per 256 depth-sorted gaussians
     const uint32_t eoff = ctrl->ent_off;

@@ -10,7 +10,8 @@ struct BlendArgs {
     int ctiles_x;
     int cell_lists;
     const uint32_t *pval; // the lists: gaussian ids (cell_lists: | tile mask << 28)
-    const GaussRec *rec;
+    GaussRec *rec;        // read; a deferred colour is written back into its record (staged_q2)
+    const FrameCtrl *ctrl; // col_*: what a deferred colour is evaluated from
     void *out;            // float32, or bfloat16 when out_bf16
     float *out_T;
     uint32_t *stats;      // [launch slots][BLEND_STAT_WORDS]

@@ -1,6 +1,6 @@
 // gauss_math.h — per-gaussian device math shared by the fused preprocess kernel and the stand-alone helpers.
 // Every function keeps the reference's fp32 operation order (file:line cited); translation units that include
-// this header are built with -ffp-contract=off.
+// this header are built with -ffp-contract=off (blend.hip, which is not, uses sh_eval only: it carries its own pragma).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -34,9 +34,16 @@ __device__ __forceinline__ void cov3d_of(const float ls[3], const float4 q, floa
         for (int j = 0; j < 3; ++j) cov[i][j] = M[i][0] * M[j][0] + M[i][1] * M[j][1] + M[i][2] * M[j][2];
 }
 
-// sh_to_rgb, spherical_harmonics.py:27-73; sh = 48 floats [16][3] of one gaussian, already in registers.
-__device__ __forceinline__ void sh_eval(const float p[3], const float *sh, const float cc[3], int degree, float rgb[3])
+// sh_to_rgb, spherical_harmonics.py:27-73, for one gaussian.  `get(e)` returns element e = 3 k + c of its [16][3] coefficient row.
+// The evaluation walks the row in MEMORY order (coefficient-major), each element consumed once into its channel's running sums, so a
+// caller that loads the row 16 B at a time needs only a few of its 48 values in registers at once (the blend evaluates deferred
+// colours inside a 64-VGPR kernel); per channel the operations and their association are the reference's:
+//   col = sh0 c0;  col += ((-c1 y) sh1 + (c1 z) sh2) - (c1 x) sh3;  col += (((t4 + t5) + t6) + t7) + t8;  col += ((...(t9 + t10) ... ) + t15)
+// with t_k = basis_k sh_k, basis_k written exactly as spherical_harmonics.py:45-65 writes it; + 0.5, clamp to [0, 1] (:69-71, Q7).
+template <typename Get>
+__device__ __forceinline__ void sh_eval_with(const float p[3], Get get, const float cc[3], int degree, float rgb[3])
 {
+#pragma clang fp contract(off)  // also where the including file is built with contraction on (blend.hip evaluates deferred colours)
     const float d0 = p[0] - cc[0], d1 = p[1] - cc[1], d2 = p[2] - cc[2];
     const float n = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
     const float x = d0 / n, y = d1 / n, z = d2 / n;
@@ -46,35 +53,65 @@ __device__ __forceinline__ void sh_eval(const float p[3], const float *sh, const
     const float k30 = -0.5900435899266435f, k31 = 2.890611442640554f, k32 = -0.4570457994644658f,
                 k33 = 0.3731763325901154f, k34 = -0.4570457994644658f, k35 = 1.445305721320277f,
                 k36 = -0.5900435899266435f;
+    float col[3], part[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-#define SHC(k) sh[(k) * 3 + c]
-        float col = SHC(0) * c0;
-        if (degree > 0) {  // :45-46
-            col = col + (((nc1 * y) * SHC(1) + (c1 * z) * SHC(2)) - (c1 * x) * SHC(3));
-            if (degree > 1) {  // :48-55
-                const float t4 = ((k20 * x) * y) * SHC(4);
-                const float t5 = ((k21 * y) * z) * SHC(5);
-                const float t6 = (k22 * (((2.0f * z) * z - x * x) - y * y)) * SHC(6);
-                const float t7 = ((k23 * x) * z) * SHC(7);
-                const float t8 = (k24 * (x * x - y * y)) * SHC(8);
-                col = col + ((((t4 + t5) + t6) + t7) + t8);
-                if (degree > 2) {  // :56-65
-                    const float t9 = ((k30 * y) * ((3.0f * x) * x - y * y)) * SHC(9);
-                    const float t10 = (((k31 * x) * y) * z) * SHC(10);
-                    const float t11 = ((k32 * y) * (((4.0f * z) * z - x * x) - y * y)) * SHC(11);
-                    const float t12 = ((k33 * z) * (((2.0f * z) * z - (3.0f * x) * x) - (3.0f * y) * y)) * SHC(12);
-                    const float t13 = ((k34 * x) * (((4.0f * z) * z - x * x) - y * y)) * SHC(13);
-                    const float t14 = ((k35 * z) * (x * x - y * y)) * SHC(14);
-                    const float t15 = ((k36 * x) * (x * x - (3.0f * y) * y)) * SHC(15);
-                    col = col + ((((((t9 + t10) + t11) + t12) + t13) + t14) + t15);
-                }
+    for (int c = 0; c < 3; ++c) col[c] = get(c) * c0;
+    if (degree > 0) {  // :45-46
+        const float b1 = nc1 * y, b2 = c1 * z, b3 = c1 * x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) part[c] = b1 * get(3 + c);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) part[c] = part[c] + b2 * get(6 + c);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) col[c] = col[c] + (part[c] - b3 * get(9 + c));
+        if (degree > 1) {  // :48-55
+            const float xx = x * x, yy = y * y;
+            const float b4 = (k20 * x) * y, b5 = (k21 * y) * z, b6 = k22 * (((2.0f * z) * z - xx) - yy), b7 = (k23 * x) * z,
+                        b8 = k24 * (xx - yy);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) part[c] = b4 * get(12 + c);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) part[c] = part[c] + b5 * get(15 + c);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) part[c] = part[c] + b6 * get(18 + c);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) part[c] = part[c] + b7 * get(21 + c);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) col[c] = col[c] + (part[c] + b8 * get(24 + c));
+            if (degree > 2) {  // :56-65
+                const float b9 = (k30 * y) * ((3.0f * x) * x - yy), b10 = ((k31 * x) * y) * z,
+                            b11 = (k32 * y) * (((4.0f * z) * z - xx) - yy),
+                            b12 = (k33 * z) * (((2.0f * z) * z - (3.0f * x) * x) - (3.0f * y) * y),
+                            b13 = (k34 * x) * (((4.0f * z) * z - xx) - yy), b14 = (k35 * z) * (xx - yy),
+                            b15 = (k36 * x) * (xx - (3.0f * y) * y);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) part[c] = b9 * get(27 + c);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) part[c] = part[c] + b10 * get(30 + c);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) part[c] = part[c] + b11 * get(33 + c);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) part[c] = part[c] + b12 * get(36 + c);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) part[c] = part[c] + b13 * get(39 + c);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) part[c] = part[c] + b14 * get(42 + c);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) col[c] = col[c] + (part[c] + b15 * get(45 + c));
             }
         }
-#undef SHC
-        col = col + 0.5f;                                     // :69
-        rgb[c] = col < 0.0f ? 0.0f : (col > 1.0f ? 1.0f : col);  // :71 (Q7)
     }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = col[c] + 0.5f;                        // :69
+        rgb[c] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);     // :71 (Q7)
+    }
+}
+
+// sh = 48 floats [16][3] of one gaussian, already in registers
+__device__ __forceinline__ void sh_eval(const float p[3], const float *sh, const float cc[3], int degree, float rgb[3])
+{
+    sh_eval_with(p, [sh](int e) { return sh[e]; }, cc, degree, rgb);
 }
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }

@@ -11,7 +11,7 @@ namespace gsr {
 
 // ---------------------------------------------------------------------------------------------
 // Device control block at the head of the workspace.  Zeroed at the start of every frame.
-// The first 40 bytes are GsrStats verbatim.
+// The first 48 bytes are GsrStats verbatim.
 // ---------------------------------------------------------------------------------------------
 struct FrameCtrl {
     uint32_t n_visible;     // V  (written by the first depth-sort scatter pass)
@@ -22,6 +22,7 @@ struct FrameCtrl {
     uint32_t sort_passes;   // depth-sort plan of this frame (sort.hip): passes it needs (1..4) — the sorted ids end up in val[sort_passes & 1]
     unsigned long long wave_entries;  // (quadrant, entry) pairs evaluated by the blend   } totals of blend_stats[], filled in
     unsigned long long fetched_entries;  // list entries staged by the blend              } by gsr_read_stats
+    unsigned long long colour_evals;     // deferred colours evaluated by the blend       }
     uint32_t digit_tot[512]; // per-digit totals of the radix pass in flight
     uint32_t stats_off;      // byte offset of blend_stats[] from this struct, and the number of launch slots the last
     uint32_t stats_slots;    // blend filled (tile_order_kernel writes both; 0 = no blend since the frame was reset)
@@ -32,6 +33,14 @@ struct FrameCtrl {
     uint32_t n_records;      // multi-GPU shard: records entering the depth sort (= this rank's visible gaussians; preprocess.hip)
     uint32_t ent_off;        // coarse binning without expansion: byte offset (from this struct) of the emit workgroups' partial counts
                              // of tile-list entries; gsr_read_stats totals them into n_pairs.  0: n_pairs is already final.
+    // deferred colour (GsrOptions.colour_stage = 0): what the blend needs to evaluate sh_to_rgb for a gaussian it stages — written by
+    // the preprocess kernel's workgroup 0 after the clear, so that gsr_blend (which is handed no scene) finds it in the workspace
+    const float *col_means;  // GsrScene.means
+    const void *col_sh;      // GsrScene.sh
+    float col_cc[3];         // GsrCamera.cam_center
+    int32_t col_degree;      // GsrScene.sh_degree
+    int32_t col_sh16;        // GsrScene.sh_dtype
+    uint32_t _pad0;
     uint32_t depth_key_max;  // maximum of the frame's valid depth keys (pass-0 histogram).  Cleared with the frame AND by the pass-0
                              // rowscan once consumed (gsr_bin_sort may be repeated on one gsr_preprocess).
     // ---- everything below survives the per-frame clear of a frame rendered with GsrOptions.keep_flags (and of the later views
@@ -41,7 +50,7 @@ struct FrameCtrl {
     uint32_t batch_sort_passes;  // most radix passes any frame's depth sort has needed
     uint32_t _pad1;
 };
-constexpr int BLEND_STAT_WORDS = 8;  // per launch slot: [0..3] evaluated entries of waves 0..3, [4] staged entries
+constexpr int BLEND_STAT_WORDS = 8;  // per launch slot: [0..3] evaluated entries of waves 0..3, [4] staged entries, [5] deferred colours evaluated
 
 // Per-gaussian record consumed by pair emission and the blend (48 B, three 16-B loads):
 //   q0 = {mean_x, mean_y, -B/(2C), -B/(2A)}   the two ratios locate the edge maxima in footprint.h

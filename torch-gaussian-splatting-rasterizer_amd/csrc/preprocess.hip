@@ -230,6 +230,24 @@ __device__ __forceinline__ uint32_t pack_rect8(const GeoOut &g)
     return (uint32_t)(g.tx0 & 255) | ((uint32_t)(g.ty0 & 255) << 8) | ((uint32_t)((g.tx1 - 1) & 255) << 16) | ((uint32_t)((g.ty1 - 1) & 255) << 24);
 }
 
+// Frame reset, by workgroup 0 of the frame's first kernel: nothing in that kernel reads FrameCtrl and every later kernel of the frame
+// is stream-ordered behind it (a hipMemsetAsync costs two blit kernels and a dispatch bubble, ~20 us).  Then what a blend that
+// evaluates colours itself needs to know (GsrOptions.colour_stage; gsr_blend is handed no scene).
+template <int THREADS>
+__device__ __forceinline__ void frame_reset(uint32_t *ctrl_words, int ctrl_reset_words, const GsrScene &sc, const Cam &cam)
+{
+    for (int w = threadIdx.x; w < ctrl_reset_words; w += THREADS) ctrl_words[w] = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        FrameCtrl *c = reinterpret_cast<FrameCtrl *>(ctrl_words);
+        c->col_means = sc.means;
+        c->col_sh = sc.sh;
+        c->col_cc[0] = cam.cc[0]; c->col_cc[1] = cam.cc[1]; c->col_cc[2] = cam.cc[2];
+        c->col_degree = sc.sh_degree;
+        c->col_sh16 = sc.sh_dtype;
+    }
+}
+
 // Whole frame: one thread per gaussian.
 #ifndef GSR_PRE_THREADS
 #define GSR_PRE_THREADS 256
@@ -242,24 +260,25 @@ constexpr int PRE_THREADS = GSR_PRE_THREADS;
 // of spill and is 3-5 % slower (0.158 vs 0.150 ms on the Morton-ordered bench scene, the latter measured at 76 VGPRs / 6 waves).
 // The wave-wide row loads give fp16 nothing (0.150 ms with and without: six per-lane loads at a 96-B stride are already cheap),
 // so only fp32 has them.
-template <bool DEBUG, bool SH16>
-__global__ __launch_bounds__(PRE_THREADS, (SH16 && !DEBUG) ? 6 : 4) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, GaussRec *__restrict__ rec,
+// COLOUR = false (GsrOptions.colour_stage = 0): the colour is left to the blend — the record's rgb holds the "not evaluated" mark
+// (negative: a colour is clamped to [0, 1], Q7) and the 192-B SH row is not touched here: 44 B read per gaussian instead of up to 236.
+constexpr float COLOUR_PENDING = -1.0f;
+template <bool DEBUG, bool SH16, bool COLOUR>
+__global__ __launch_bounds__(PRE_THREADS, !COLOUR ? 8 : (SH16 && !DEBUG) ? 6 : 4) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, GaussRec *__restrict__ rec,
                                                          ushort4 *__restrict__ rect, uint32_t *__restrict__ rect8, uint32_t *__restrict__ depth_key,
                                                          GsrDebugOut dbg,
                                                          uint32_t *__restrict__ ctrl_words, int ctrl_reset_words, int packed_rect, int sh_dense_min)
 {
-    constexpr bool WAVE_SH = !DEBUG && !SH16;  // fp32 rows of a dense wave go through LDS (load_sh48_wave)
+    static_assert(COLOUR || !DEBUG, "the debug outputs include rgb");
+    constexpr bool WAVE_SH = COLOUR && !DEBUG && !SH16;  // fp32 rows of a dense wave go through LDS (load_sh48_wave)
     __shared__ float4 s_sh[WAVE_SH ? (PRE_THREADS / 64) * 384 : 1];
-    // frame reset: nothing in this kernel reads FrameCtrl and every later kernel of the frame is stream-ordered behind it,
-    // so workgroup 0 clears the counters here (a hipMemsetAsync costs two blit kernels and a dispatch bubble, ~20 us)
-    if (blockIdx.x == 0)
-        for (int w = threadIdx.x; w < ctrl_reset_words; w += PRE_THREADS) ctrl_words[w] = 0u;
+    if (blockIdx.x == 0) frame_reset<PRE_THREADS>(ctrl_words, ctrl_reset_words, sc, cam);
     const int64_t i = (int64_t)blockIdx.x * PRE_THREADS + threadIdx.x;  // the constant, not blockDim.x: that would pull in the hidden kernarg block
     if (i >= sc.n) return;
     // (the gaussian id is not written: pass 0 of the depth sort synthesises the identity payload, 8 B per gaussian less traffic)
     const GeoOut g = geometry_one<DEBUG>(sc, cam, compat, no_cull, row_begin, row_step, keep_ref_drawn, dbg, i);
-    float rgb[3] = {0.f, 0.f, 0.f};
-    bool coloured = false;
+    float rgb[3] = {COLOUR_PENDING, COLOUR_PENDING, COLOUR_PENDING};
+    bool coloured = !COLOUR;
     if constexpr (WAVE_SH) {
         const int lane = threadIdx.x & 63;
         const int64_t i0 = i - lane;
@@ -343,7 +362,7 @@ __device__ __forceinline__ uint32_t block_append_256(bool flag, uint32_t *s_wave
     return pos;
 }
 
-template <bool SH16>
+template <bool SH16, bool COLOUR>
 __global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step,
                                                                GaussRec *__restrict__ rec, ushort4 *__restrict__ rect,
                                                                uint32_t *__restrict__ run_key, uint32_t *__restrict__ run_id,
@@ -354,8 +373,7 @@ __global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, Cam 
     __shared__ uint32_t s_id[SHARD_SPAN], s_key[SHARD_SPAN], s_rect8[SHARD_SPAN];
     __shared__ float s_l2op[SHARD_SPAN];
     __shared__ uint32_t s_wave[4], s_ncand, s_nvis;
-    if (blockIdx.x == 0)  // frame reset, as in preprocess_kernel
-        for (int w = threadIdx.x; w < ctrl_reset_words; w += 256) ctrl_words[w] = 0u;
+    if (blockIdx.x == 0) frame_reset<256>(ctrl_words, ctrl_reset_words, sc, cam);  // as in preprocess_kernel
     if (threadIdx.x == 0) { s_ncand = 0; s_nvis = 0; }
     const int64_t base = (int64_t)blockIdx.x * SHARD_SPAN;
     const float *V = cam.V, *F = cam.F;
@@ -440,9 +458,11 @@ __global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, Cam 
     if (threadIdx.x == 0) run_cnt[blockIdx.x] = nvis;
     for (uint32_t j = threadIdx.x; j < nvis; j += 256) {
         const int64_t i = (int64_t)s_id[j];
-        const float pm[3] = {sc.means[3 * i], sc.means[3 * i + 1], sc.means[3 * i + 2]};
-        float rgb[3];
-        colour_one<SH16>(sc, cam, i, pm, rgb);
+        float rgb[3] = {COLOUR_PENDING, COLOUR_PENDING, COLOUR_PENDING};
+        if constexpr (COLOUR) {
+            const float pm[3] = {sc.means[3 * i], sc.means[3 * i + 1], sc.means[3 * i + 2]};
+            colour_one<SH16>(sc, cam, i, pm, rgb);
+        }
         rec[i].q2 = make_float4(s_l2op[j], rgb[0], rgb[1], rgb[2]);
         run_key[base + j] = s_key[j];
         run_id[base + j] = (uint32_t)i;
@@ -525,28 +545,31 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
     // GsrOptions.sh_dense_min overrides it for experiments (65 = never).  Swept on the bench frame (file order / Morton order): >= 56: 0.273 / 0.216 ms,
     // >= 48: 0.275 / 0.216, >= 32: 0.359 / 0.202, >= 16: 0.381 / 0.205, never: 0.288 / 0.241.
     const int sh_dense_min = opts.sh_dense_min > 0 ? opts.sh_dense_min : 48;
-#define GSR_LAUNCH_PRE(DBG, H16)                                                                                              \
-    hipLaunchKernelGGL((preprocess_kernel<DBG, H16>), dim3(grid), dim3(PRE_THREADS), 0, s, scene, k, opts.reference_compat,     \
+    const bool colour = opts.colour_stage == 1;  // 0: the blend evaluates a gaussian's colour when a tile first stages it
+#define GSR_LAUNCH_PRE(DBG, H16, COL)                                                                                         \
+    hipLaunchKernelGGL((preprocess_kernel<DBG, H16, COL>), dim3(grid), dim3(PRE_THREADS), 0, s, scene, k, opts.reference_compat,     \
                        opts.no_footprint_cull, opts.tile_row_begin, row_step, opts.draw_limit > 0 ? 1 : 0, ws.rec, ws.rect,     \
                        ws.rect8[0], ws.key[0], d, reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, packed, sh_dense_min)
     // debug outputs cover every gaussian: for a shard (below) that is a pass of its own, whose other outputs are then
     // overwritten
-    if (dbg) { if (h16) GSR_LAUNCH_PRE(true, true); else GSR_LAUNCH_PRE(true, false); }
+    if (dbg) { if (h16) GSR_LAUNCH_PRE(true, true, true); else GSR_LAUNCH_PRE(true, false, true); }
     if (shard_compact(opts)) {
         const unsigned sgrid = (unsigned)((scene.n + SHARD_SPAN - 1) / SHARD_SPAN);
         // the workgroups' runs go to the "out" halves of the depth sort's ping-pong buffers, idle until its pass 0 scatters
         // into them (after shard_compact_kernel has read them); their lengths to blk_sum, idle until the pair count
         uint32_t *run_cnt = ws.blk_sum;
-#define GSR_LAUNCH_SHARD(H16)                                                                                                 \
-    hipLaunchKernelGGL(shard_preprocess_kernel<H16>, dim3(sgrid), dim3(256), 0, s, scene, k, opts.reference_compat,             \
+#define GSR_LAUNCH_SHARD(H16, COL)                                                                                            \
+    hipLaunchKernelGGL((shard_preprocess_kernel<H16, COL>), dim3(sgrid), dim3(256), 0, s, scene, k, opts.reference_compat,             \
                        opts.no_footprint_cull, opts.tile_row_begin, row_step, ws.rec, ws.rect, ws.key[1], ws.val[1], ws.rect8[1], \
                        run_cnt, reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, packed)
-        if (h16) GSR_LAUNCH_SHARD(true); else GSR_LAUNCH_SHARD(false);
+        if (h16) { if (colour) GSR_LAUNCH_SHARD(true, true); else GSR_LAUNCH_SHARD(true, false); }
+        else { if (colour) GSR_LAUNCH_SHARD(false, true); else GSR_LAUNCH_SHARD(false, false); }
 #undef GSR_LAUNCH_SHARD
         hipLaunchKernelGGL(shard_compact_kernel, dim3(sgrid), dim3(256), 0, s, ws.key[1], ws.val[1], ws.rect8[1], run_cnt, ws.key[0], ws.val[0],
                            ws.rect8[0], &ws.ctrl->n_records, packed);
     } else if (!dbg) {
-        if (h16) GSR_LAUNCH_PRE(false, true); else GSR_LAUNCH_PRE(false, false);
+        if (h16) { if (colour) GSR_LAUNCH_PRE(false, true, true); else GSR_LAUNCH_PRE(false, true, false); }
+        else { if (colour) GSR_LAUNCH_PRE(false, false, true); else GSR_LAUNCH_PRE(false, false, false); }
     }
 #undef GSR_LAUNCH_PRE
     GSR_HIP(hipGetLastError());
