@@ -544,7 +544,10 @@ def test_blend_counters_describe_the_last_blend(G):
     R.render(cam)
     first = dict(R.last_stats)
     R.render(cam)
-    assert R.last_stats == first and first["wave_entries"] > 0
+    same = lambda a, b: all(a[k] == b[k] for k in a if k != "colour_evals")
+    assert same(R.last_stats, first) and first["wave_entries"] > 0
+    # deferred colours: tiles racing for a gaussian may each evaluate it (same value), so the count varies a little from run to run
+    assert 0 < first["colour_evals"] <= first["fetched_entries"] and abs(R.last_stats["colour_evals"] - first["colour_evals"]) <= 0.05 * first["colour_evals"]
     R.render(cam, G.renderer.make_options(blend_impl=1))
     assert first["fetched_entries"] <= R.last_stats["fetched_entries"] <= 1.05 * first["fetched_entries"]   # batches of 256 vs 128
     assert abs(R.last_stats["wave_entries"] - first["wave_entries"]) <= 0.05 * first["wave_entries"]
@@ -555,7 +558,7 @@ def test_blend_counters_describe_the_last_blend(G):
     check(lib.gsr_preprocess(C.byref(sc), C.byref(cam), C.byref(opts), ws.data_ptr(), ws.numel(), None, sp))
     check(lib.gsr_bin_sort(R.scene.n, C.byref(cam), C.byref(opts), R.max_pairs, ws.data_ptr(), ws.numel(), sp))
     st = R.stats()
-    assert st["wave_entries"] == 0 and st["fetched_entries"] == 0 and st["n_pairs"] == first["n_pairs"]
+    assert st["wave_entries"] == 0 and st["fetched_entries"] == 0 and st["colour_evals"] == 0 and st["n_pairs"] == first["n_pairs"]
     # shards: every tile is blended by exactly one shard (lists can only grow where a rect falls under the per-tile test)
     tot = 0
     for r in range(3):
@@ -906,7 +909,7 @@ def test_hand_scheduled_blend_walk_equals_the_plain_kernel(G):
             sc = dict(R.last_stats)
             d = R.render(cam, mk(blend_impl=1, **kw))
             assert torch.equal(c, d), kw
-            assert all(sc[k] == R.last_stats[k] for k in sc if k != "fetched_entries") and sc["fetched_entries"] <= R.last_stats["fetched_entries"], kw
+            assert all(sc[k] == R.last_stats[k] for k in sc if k not in ("fetched_entries", "colour_evals")) and sc["fetched_entries"] <= R.last_stats["fetched_entries"], kw
             a, Ta = R.render(cam, mk(**kw), return_T=True)
             sa = dict(R.last_stats)
             b, Tb = R.render(cam, mk(blend_impl=1, **kw), return_T=True)
@@ -915,7 +918,7 @@ def test_hand_scheduled_blend_walk_equals_the_plain_kernel(G):
             sb = R.last_stats
             # same lists, same evaluations; the product kernel stages 128 entries per batch, the plain one 256, so a tile that
             # saturates stops fetching a little earlier in the former
-            assert all(sa[k] == sb[k] for k in sa if k != "fetched_entries") and sa["fetched_entries"] <= sb["fetched_entries"], kw
+            assert all(sa[k] == sb[k] for k in sa if k not in ("fetched_entries", "colour_evals")) and sa["fetched_entries"] <= sb["fetched_entries"], kw
 
 
 @pytest.mark.parametrize("name,prefix", [("medium", ""), ("960x540", ""), ("f3_edge.npz", "a_"), ("f3_edge.npz", "b_")])
