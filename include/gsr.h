@@ -131,6 +131,10 @@ typedef struct GsrOptions {
                                  whole-frame kernel, 2 = always the three-phase kernel (csrc/preprocess.hip).  Was GSR_SHARD_PREPROCESS. */
     int32_t blend_pipe_tiles; /* tile count up to which the blend runs its pipelined one-quadrant walk: 0 (default) = 1280, -1 = never
                                  (csrc/blend.hip).  Was GSR_BLEND_PIPE_TILES. */
+    int32_t no_order_hint;    /* 0 (default): tiles are launched heaviest first by what each tile's blend STAGED in the last frame rendered on
+                                 this workspace (consecutive frames of a camera path look alike; a tile saturates long before the end of
+                                 its list), falling back to the list length where that record is missing or impossible.  1: by list length
+                                 alone (rounds 1-3).  A schedule only: every order renders the same bits. */
     int32_t colour_stage;     /* where is sh_to_rgb (spherical_harmonics.py:27-73) evaluated?
                                  0 (default): in the blend, when a tile first STAGES a gaussian (its 192-B SH row is read and its colour
                                  evaluated then, and remembered in the gaussian's record for the tiles that stage it later): gaussians

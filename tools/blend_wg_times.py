@@ -28,7 +28,7 @@ for _ in range(4):
     R.enqueue(cam, opts, out)
 torch.cuda.synchronize()
 ws = R._workspace(W, H).cpu().numpy()
-off, slots = (int(x) for x in ws[2088:2096].view(np.uint32))      # FrameCtrl.stats_off / stats_slots (gsr_internal.h)
+off, slots = (int(x) for x in ws[2096:2104].view(np.uint32))      # FrameCtrl.stats_off / stats_slots (gsr_internal.h)
 st = ws[off: off + slots * 32].view(np.uint32).reshape(slots, 8)
 live = st[:, 6] != 0
 t0 = st[live, 5].astype(np.int64); t1 = st[live, 6].astype(np.int64)

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""A/B of whole-frame variants selected by environment switches the library reads per call (e.g. GSR_FINE_BINNING=1),
+"""A/B of whole-frame variants selected by GsrOptions fields (e.g. fine_binning=1, saturation_rule=1, colour_stage=1),
 interleaved rounds in ONE process (MI355X guide, rule 24): per variant the three stage times (events around gsr_preprocess /
 gsr_bin_sort / gsr_blend), median over rounds, plus bit-identity of the frames.
-usage: tools/frame_ab.py [--workload bicycle] [--rounds 12] VARIANT [VARIANT ...]     VARIANT = name[:ENV=VALUE[,ENV=VALUE]]"""
+usage: tools/frame_ab.py [--workload bicycle] [--rounds 12] VARIANT [VARIANT ...]     VARIANT = name[:field=value[,field=value]]
+(GSR_MORTON=0: the scene in file order instead of the loaders' Morton order)"""
 import argparse
 import ctypes as C
 import os
@@ -31,37 +32,30 @@ def main():
     cols, cam_list, n, W, H, _ = bench.build_workload(a.workload, a, a.gaussians)
     packed = utils.pack_gaussians(cols)
     del cols
-    scene = renderer.GaussianScene.from_packed(packed, device=dev, spatial_order=os.environ.get("GSR_MORTON") == "1")  # A/B of the loader option
+    scene = renderer.GaussianScene.from_packed(packed, device=dev, spatial_order=os.environ.get("GSR_MORTON", "1") == "1")  # A/B of the loader option
     del packed
     cam = renderer.make_camera(*cam_list[0])
     variants = []
     for v in a.variants:
         name, _, envs = v.partition(":")
-        variants.append((name, dict(e.split("=") for e in envs.split(",") if e)))
-    keys = sorted({k for _, e in variants for k in e})
-
-    def select(env):
-        for k in keys:
-            os.environ.pop(k, None)
-        os.environ.update(env)
+        kw = {k: (float(v) if "." in v or "e" in v else int(v)) for k, v in (e.split("=") for e in envs.split(",") if e)}
+        variants.append((name, renderer.make_options(**kw)))
 
     R = renderer.Rasterizer(scene)
     need = 0
-    for _, env in variants:  # one pair buffer that fits every variant
-        select(env)
-        need = max(need, R.fit_pairs(cam))
+    for _, o in variants:  # one pair buffer that fits every variant
+        need = max(need, R.fit_pairs(cam, o))
     R.max_pairs = need
     ws = R._workspace(W, H)
     sc = scene.c_struct()
-    opts = renderer.make_options()
     stream = torch.cuda.current_stream(dev)
     sp = int(stream.cuda_stream)
     outs = {name: torch.empty((H, W, 3), dtype=torch.float32, device=dev) for name, _ in variants}
     times = {name: [] for name, _ in variants}
     stats = {}
     for rnd in range(a.rounds + 2):
-        for name, env in variants:
-            select(env)
+        for name, o in variants:
+            opts = R.bounded(o)
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             for _ in range(2):  # the second repetition is the timed one (same variant back to back: caches warm for it)
                 ev[0].record(stream)

@@ -13,13 +13,13 @@ args = sys.argv[1:]
 workload = args.pop(0) if args and not args[0].isdigit() else "bicycle"
 n, seed = {"bicycle": (6_131_954, 361), "garden": (5_834_784, 360)}[workload]
 only = (int(args[0]), int(args[1])) if len(args) > 1 else None
-SLOTS = int(os.environ.get("GSR_SLOTS", "4"))
+SLOTS = int(os.environ.get("GSR_SLOTS", "6"))
 W, H = 1920, 1080
 cols = synthetic.mip360_like(n, seed)
 p = synthetic.ring_cameras(25)[0]
 fx = synthetic.pinhole_focal(W)
 cam = renderer.make_camera(p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H)
-scene = renderer.GaussianScene.from_columns(cols, spatial_order=os.environ.get("GSR_MORTON") == "1")  # the loader's Morton-order option
+scene = renderer.GaussianScene.from_columns(cols, spatial_order=os.environ.get("GSR_MORTON", "1") == "1")  # the loaders' default; GSR_MORTON=0: file order
 
 
 def timed(fif, opts, outs, frames=24):

@@ -86,6 +86,7 @@ class GsrOptions(C.Structure):
         ("fine_binning", C.c_int32),
         ("shard_preprocess", C.c_int32),
         ("blend_pipe_tiles", C.c_int32),
+        ("no_order_hint", C.c_int32),
         ("colour_stage", C.c_int32),
         ("sh_dense_min", C.c_int32),
     ]

@@ -63,6 +63,7 @@ size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max
     const size_t order_slots = 8 * (size_t)((ws->tiles_y + 7) / 8) * ws->tiles_x;
     ws->tile_order = static_cast<int *>(take(sizeof(int) * order_slots));
     ws->blend_stats = static_cast<uint32_t *>(take(sizeof(uint32_t) * BLEND_STAT_WORDS * order_slots));
+    ws->tile_work = static_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)ws->tiles_x * ws->tiles_y));
     ws->pair_off = nullptr;
     ws->bytes = off;
     return off;
@@ -92,6 +93,7 @@ static int check_frame(int64_t n, const GsrCamera *cam, const GsrOptions *opts, 
     if (opts->fine_binning != 0 && opts->fine_binning != 1) { set_error("bad fine_binning %d", opts->fine_binning); return GSR_ERR_BAD_ARG; }
     if (opts->shard_preprocess < 0 || opts->shard_preprocess > 2) { set_error("bad shard_preprocess %d", opts->shard_preprocess); return GSR_ERR_BAD_ARG; }
     if (opts->blend_pipe_tiles < -1) { set_error("bad blend_pipe_tiles %d", opts->blend_pipe_tiles); return GSR_ERR_BAD_ARG; }
+    if (opts->no_order_hint != 0 && opts->no_order_hint != 1) { set_error("bad no_order_hint %d", opts->no_order_hint); return GSR_ERR_BAD_ARG; }
     if (opts->colour_stage != 0 && opts->colour_stage != 1) { set_error("bad colour_stage %d", opts->colour_stage); return GSR_ERR_BAD_ARG; }
     if (opts->sh_dense_min < 0 || opts->sh_dense_min > 65) { set_error("bad sh_dense_min %d", opts->sh_dense_min); return GSR_ERR_BAD_ARG; }
     if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) { set_error("workspace must be 256-byte aligned"); return GSR_ERR_BAD_ARG; }

@@ -889,7 +889,7 @@ __device__ __forceinline__ void stat_colour_evals(uint32_t mine, uint32_t *s_col
 __global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict__ ranges, FrameCtrl *ctrl, int tiles_x,
                                                          int row_begin, int row_step, int rows, int slots_per_group,
                                                          int *__restrict__ order, uint32_t stats_off, const uint2 *__restrict__ cranges,
-                                                         int ctiles_x)
+                                                         int ctiles_x, const uint32_t *__restrict__ tile_work)
 {
     constexpr int NB = 256;
     __shared__ uint32_t bucket_cnt[NB];
@@ -903,9 +903,14 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict
     __syncthreads();
     auto tile_of = [&](int j) { return (row_begin + (g + 8 * (j / tiles_x)) * row_step) * tiles_x + (j % tiles_x); };
     // cell lists (cranges != nullptr): the length of the tile's CELL list, an upper bound of what the tile will keep of it
+    // The work of a tile is what its blend STAGES before it saturates, which its list length only bounds.  Where the last frame
+    // rendered on this workspace left that count for the tile (1 + entries; a fresh workspace holds anything), it is the better
+    // estimate — consecutive frames of a camera path look alike — as long as it is possible at all (<= the list): the order is a
+    // schedule, every permutation renders the same frame.
     auto len_of = [&](int tile) {
         const uint2 r = cranges ? cranges[(tile / tiles_x >> 1) * ctiles_x + (tile % tiles_x >> 1)] : ranges[tile];
-        return r.y - r.x;
+        const uint32_t len = r.y - r.x, w = tile_work ? tile_work[tile] : 0u;
+        return (w != 0u && w - 1u <= len) ? w - 1u : len;
     };
     // lengths < 2^24: float conversion is exact; bits >> 20 = exponent (8 bits) and 3 mantissa bits, monotone in len
     auto bucket_of = [&](uint32_t len) { return len == 0 ? (uint32_t)(NB - 1) : min((uint32_t)(NB - 2), (151u << 3) - (__float_as_uint((float)len) >> 20)); };
@@ -951,7 +956,7 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t *stat = a.stats + (size_t)blockIdx.x * BLEND_STAT_WORDS;
     if (tile < 0) {  // uniform: empty launch slot
-        if (tid < 6) stat[tid] = 0;
+        if (tid < BLEND_STAT_WORDS) stat[tid] = 0;
         return;
     }
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
@@ -1024,7 +1029,7 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
     }
 
     if (lane == 0) stat[wave] = evaluated;
-    if (tid == 0) stat[4] = fetched;
+    if (tid == 0) { stat[4] = fetched; a.tile_work[tile] = fetched + 1u; }
     stat_colour_evals(col_evals, &s_col, stat);
     if (px < a.W && py < a.H) {
         const bool drawn = px < a.xlim && py < a.ylim;  // Q1: last column / row stay black, T stays 1
@@ -1069,7 +1074,7 @@ __global__ __launch_bounds__(256 / QPW, PIPE ? 5 : 8) void blend_walk_kernel(Ble
     const unsigned long long ts0 = wall_clock64();
 #endif
     if (tile < 0) {  // uniform: empty launch slot
-        if (tid < 6) stat[tid] = 0;
+        if (tid < BLEND_STAT_WORDS) stat[tid] = 0;
         return;
     }
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
@@ -1141,7 +1146,7 @@ __global__ __launch_bounds__(256 / QPW, PIPE ? 5 : 8) void blend_walk_kernel(Ble
         stat[wave] = evaluated;
         if (QPW == 2) stat[2 + wave] = 0;
     }
-    if (tid == 0) stat[4] = fetched;
+    if (tid == 0) { stat[4] = fetched; a.tile_work[tile] = fetched + 1u; }
     stat_colour_evals(col_evals, &s_col, stat);
 #ifdef GSR_BLEND_TIMESTAMPS  // (the timestamp build reuses stat[5])
     __syncthreads();
@@ -1168,7 +1173,10 @@ __global__ __launch_bounds__(256 / QPW, PIPE ? 5 : 8) void blend_walk_kernel(Ble
 }
 
 // two quadrants per wave from this many tiles per launch on (measured: 4080 tiles better with two, 2040 with one); below, one quadrant per wave (see blend_walk_kernel)
-constexpr int BLEND_HALF_MIN_TILES = 3000;
+#ifndef GSR_BLEND_HALF_MIN_TILES
+#define GSR_BLEND_HALF_MIN_TILES 3000
+#endif
+constexpr int BLEND_HALF_MIN_TILES = GSR_BLEND_HALF_MIN_TILES;  // (the macro: tools/ A/B builds)
 // the pipelined one-quadrant walk (96 VGPRs: 5 waves per SIMD = 1280 four-wave workgroups resident) up to this many tiles per launch;
 // GsrOptions.blend_pipe_tiles overrides it (experiments and tests: -1 switches the variant off)
 constexpr int BLEND_PIPE_MAX_TILES = 1280;
@@ -1187,6 +1195,7 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     a.out = out_image;
     a.out_T = out_T;
     a.stats = ws.blend_stats;
+    a.tile_work = ws.tile_work;
     a.W = cam.width; a.H = cam.height;
     a.xlim = opts.reference_compat ? cam.width - 1 : cam.width;
     a.ylim = opts.reference_compat ? cam.height - 1 : cam.height;
@@ -1207,7 +1216,7 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(256), 0, s, ws.ranges, ws.ctrl, a.tiles_x, a.row_begin, a.row_step, a.rows,
                        slots_per_group, ws.tile_order,
                        (uint32_t)(reinterpret_cast<const char *>(ws.blend_stats) - reinterpret_cast<const char *>(ws.ctrl)),
-                       a.cell_lists ? ws.cranges : nullptr, ws.ctiles_x);
+                       a.cell_lists ? ws.cranges : nullptr, ws.ctiles_x, opts.no_order_hint ? nullptr : ws.tile_work);
     if (opts.accum_dtype == 1) hipLaunchKernelGGL(blend_kernel<true>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     else if (opts.blend_impl == 1) hipLaunchKernelGGL(blend_kernel<false>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
     else if (a.rows * a.tiles_x >= BLEND_HALF_MIN_TILES) hipLaunchKernelGGL((blend_walk_kernel<2, false>), dim3(8u * (unsigned)slots_per_group), dim3(128), 0, s, a);

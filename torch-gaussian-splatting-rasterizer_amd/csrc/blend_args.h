@@ -15,6 +15,7 @@ struct BlendArgs {
     void *out;            // float32, or bfloat16 when out_bf16
     float *out_T;
     uint32_t *stats;      // [launch slots][BLEND_STAT_WORDS]
+    uint32_t *tile_work;  // [tiles] 1 + entries staged: next frame's launch-order hint
     const int *order;     // tile launch order (tile_order_kernel), -1 = empty slot
     int W, H;
     int xlim, ylim;       // pixels x < xlim, y < ylim are drawn (W-1/H-1 in reference_compat: Q1)

@@ -84,6 +84,8 @@ struct Workspace {
     uint2 *ranges;        // [tiles]
     uint2 *cranges;       // [ctiles]  coarse binning: [begin, end) of every 32x32 cell's list in the sorted pair array
     int *tile_order;      // [8 * ceil(tiles_y/8) * tiles_x] blend launch order
+    uint32_t *tile_work;  // [tiles] 1 + entries the tile's blend staged in the LAST frame rendered on this workspace (0 / garbage: unknown):
+                          // the launch-order hint of the next frame (blend.hip, tile_order_kernel); never cleared, never trusted
     uint32_t *blend_stats; // [tile_order slots][BLEND_STAT_WORDS] per-workgroup counters: plain stores, no atomics (40 k
                           // same-address atomics per frame put a 0.45 ms floor under the blend kernel)
     int64_t n;

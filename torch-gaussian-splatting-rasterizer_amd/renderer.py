@@ -172,7 +172,7 @@ def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_r
                  output_layout: int = 0, no_footprint_cull: bool = False, blend_impl: int = 0, draw_limit: int = 0,
                  output_bf16: bool = False, depth_sort_passes: int = 0, keep_flags: bool = False, accum_bf16: bool = False,
                  saturation_rule: int = 0, fine_binning: bool = False, shard_preprocess: int = 0, blend_pipe_tiles: int = 0,
-                 sh_dense_min: int = 0, colour_stage: int = 0) -> GsrOptions:
+                 sh_dense_min: int = 0, colour_stage: int = 0, no_order_hint: bool = False) -> GsrOptions:
     o = _lib.default_options()
     o.reference_compat = 1 if reference_compat else 0
     o.early_out_T = float(early_out_T)
@@ -191,6 +191,7 @@ def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_r
     o.shard_preprocess = int(shard_preprocess)    # preprocess; tile bound of the pipelined blend walk (-1 = never); dense-wave SH threshold
     o.blend_pipe_tiles = int(blend_pipe_tiles)
     o.sh_dense_min = int(sh_dense_min)
+    o.no_order_hint = 1 if no_order_hint else 0   # blend launch order by list length alone (default: by what each tile staged last frame)
     o.colour_stage = int(colour_stage)            # 0: sh_to_rgb when a tile first stages the gaussian (blend); 1: for every visible gaussian (preprocess)
     return o
 
