@@ -179,7 +179,8 @@ def stage_profile(R, scene, cam, opts, out_shape, tiles, reps, sh_half, prof, de
     """Per-stage times of one frame (HIP events around gsr_preprocess / gsr_bin_sort / gsr_blend on ONE stream, mean over `reps`
     frames after 3 untimed ones) and the roofline object of the dominant kernel, the blend.
 
-    roofline.achieved / peak / frac are the CONTRACT figure: algorithmic bytes 40 E + 12 P + 8 tiles per launch
+    roofline.achieved / peak / frac are the CONTRACT figure: algorithmic bytes 40 E + 12 P + 8 tiles (+ 216 per colour
+    the blend evaluated itself: the SH row SURVEY prices at 192 B, the mean, the write-back) per launch
     over the kernel's time against 8 TB/s.  The kernel is not bound by HBM but by vector-ALU issue (exact per-pixel evaluation:
     ~13 issue slots per evaluated (8x8 quadrant, entry), a quarter-rate v_exp_f32 among them), so `bound` says "valu" and the
     fractions that describe it ride along: valu_issue_frac (VALU wave-instructions per launch, from the committed rocprofv3
@@ -211,11 +212,15 @@ def stage_profile(R, scene, cam, opts, out_shape, tiles, reps, sh_half, prof, de
     st = R.stats()
     stage = [float(np.mean([e[k].elapsed_time(e[k + 1]) for e in ev])) for k in range(3)]
     E, P, V = st["fetched_entries"], out.shape[0] * out.shape[1], st["n_visible"]  # E = entries actually fetched
-    blend_bytes = 40.0 * E + 12.0 * P + 8.0 * tiles
-    # preprocess: 44 B of geometry per gaussian; the SH row (192 B, 96 B as fp16) and the outputs (48-B record + key + packed rect
-    # + the slack of the 64 B SURVEY.md §8(d) allows) only for the V visible ones — culled and off-screen gaussians never read
-    # their SH row (rounds 1-3 priced every gaussian at 236 B: a figure that could exceed the HBM peak)
-    pre_bytes = 44.0 * n + ((96.0 if sh_half else 192.0) + 64.0) * V
+    # + the colour of every gaussian the blend evaluated itself (GsrOptions.colour_stage = 0: the 192-B SH row — 96 B as fp16 — and
+    # the 12-B mean are read when a tile first stages the gaussian, 12 B of colour written back): those bytes left the preprocess
+    C_ev = st.get("colour_evals", 0)
+    blend_bytes = 40.0 * E + 12.0 * P + 8.0 * tiles + ((96.0 if sh_half else 192.0) + 12.0 + 12.0) * C_ev
+    # preprocess: 44 B of geometry per gaussian; the outputs (48-B record + key + packed rect + the slack of the 64 B SURVEY.md §8(d)
+    # allows) only for the V visible ones; the SH row (192 B, 96 B as fp16) only where the preprocess evaluates colours
+    # (colour_stage = 1) and then only for visible gaussians (rounds 1-3 priced every gaussian at 236 B: a figure that could
+    # exceed the HBM peak)
+    pre_bytes = 44.0 * n + 64.0 * V + (0.0 if C_ev else (96.0 if sh_half else 192.0) * V)
     # bin + sort, as THIS design moves them: depth sort of the V visible keys (pass 0 reads all N keys twice —
     # histogram, scatter — and writes V (key, id, packed rect) triples; each later pass reads V keys for its histogram, then reads
     # and writes the V triples), pair count / emit (reads the V ids + rects, writes D (cell key, value) pairs), the 2-pass cell
@@ -257,7 +262,8 @@ def stage_profile(R, scene, cam, opts, out_shape, tiles, reps, sh_half, prof, de
 
     stage_roofs = {
         "preprocess": stage_roof("gsr::preprocess_kernel", "hbm", pre_bytes, stage[0], prof.get("preprocess_bytes_per_launch"),
-                                 "44 N + (192 + 64) V bytes: the SH row and the outputs only for visible gaussians"),
+                                 "44 N + 64 V bytes (+ 192 V when the preprocess evaluates the colours, GsrOptions.colour_stage = 1): geometry of "
+                                 "every gaussian, the outputs of the visible ones"),
         "bin_sort": stage_roof("gsr::radix_* + pair_* + tile_* (the stage's ~20 dispatches together)", "hbm", sort_bytes, stage[1],
                                prof.get("bin_sort_bytes_per_frame"),
                                "bytes as this design moves them (bench.py stage_profile); the stage is bound by the latency of its "
