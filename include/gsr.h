@@ -210,7 +210,9 @@ int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_
 /* Stage 3 — front-to-back compositing of every tile list: rasterize.py:436-446 (driver loop + skip guard)
  * and :255-305 (rasterize_gaussian).  out_image layout per opts->output_layout; out_final_T [H,W] may be NULL.
  * n and max_pairs must be the values given to the earlier stages (the library keeps no state; they fix the
- * workspace layout). */
+ * workspace layout).  With GsrOptions.colour_stage = 0 (default) this stage evaluates sh_to_rgb (spherical_harmonics.py:27-73) for
+ * the gaussians its tiles stage: it reads the scene's `means` and `sh` arrays through the pointers gsr_preprocess left in the
+ * workspace, so those arrays must still be alive and unchanged. */
 int gsr_blend(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs, void *workspace,
               size_t workspace_bytes, void *out_image /* float32 or bfloat16, opts->output_dtype */, float *out_final_T,
               void *stream);

@@ -907,9 +907,12 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict
     // rendered on this workspace left that count for the tile (1 + entries; a fresh workspace holds anything), it is the better
     // estimate — consecutive frames of a camera path look alike — as long as it is possible at all (<= the list): the order is a
     // schedule, every permutation renders the same frame.
-    auto len_of = [&](int tile) {
+    auto list_len = [&](int tile) {
         const uint2 r = cranges ? cranges[(tile / tiles_x >> 1) * ctiles_x + (tile % tiles_x >> 1)] : ranges[tile];
-        const uint32_t len = r.y - r.x, w = tile_work ? tile_work[tile] : 0u;
+        return r.y - r.x;
+    };
+    auto len_of = [&](int tile) {
+        const uint32_t len = list_len(tile), w = tile_work ? tile_work[tile] : 0u;
         return (w != 0u && w - 1u <= len) ? w - 1u : len;
     };
     // lengths < 2^24: float conversion is exact; bits >> 20 = exponent (8 bits) and 3 mantissa bits, monotone in len
@@ -917,7 +920,7 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict
     uint32_t longest = 0;
     for (int j = tid; j < n; j += 256) {
         const uint32_t len = len_of(tile_of(j));
-        longest = max(longest, len);
+        longest = max(longest, list_len(tile_of(j)));  // GsrStats.max_list_len is the list, not the estimate
         atomicAdd(&bucket_cnt[bucket_of(len)], 1u);
     }
     __syncthreads();
