@@ -159,7 +159,17 @@ def main():
             # the loader's Morton order: the same frame, bit for bit unless two visible gaussians share a depth exactly
             Rm = renderer.Rasterizer(renderer.GaussianScene.from_packed(packed, sh_degree=degree, spatial_order=True))
             mimg = Rm.render(cam)
-            close(mimg.cpu().numpy(), oimg)
+            # gaussians at EXACTLY equal depth (the generator plants some) are drawn in scene-index order, which the reference
+            # leaves undefined: with ties among the visible ones the oracle is fed the arrays in the scene's order (same gaussians, same
+            # tie order) — case-seed 1149722072972822031: 20 ties among 40 412 visible, 0.0086 apart from the file-order frame
+            zc = orc.preprocess(packed, ocam, sh_degree=degree)["cam_means"][:, 2]
+            zv = zc[zc >= 0.2]
+            if len(zv) != len(np.unique(zv)):
+                mo = Rm.scene.order
+                moimg, _, _ = orc.render({k: np.ascontiguousarray(v[mo]) for k, v in packed.items()}, ocam, sh_degree=degree, want_T=True)
+                close(mimg.cpu().numpy(), moimg)
+            else:
+                close(mimg.cpu().numpy(), oimg)
             R.render(cam)
             assert Rm.last_stats["n_visible"] == R.last_stats["n_visible"] and Rm.last_stats["n_pairs"] == R.last_stats["n_pairs"], "spatial order changes the lists"
             half = renderer.Rasterizer(renderer.GaussianScene.from_packed(packed, sh_degree=degree, sh_half=True, spatial_order=False))

@@ -98,33 +98,54 @@ __device__ __forceinline__ ushort4 rect_of(uint32_t r, const uint32_t *sorted_id
     return COARSE ? coarse_rect(rc) : rc;
 }
 
+// One WAVE per emit block (EMIT_THREADS = 256 consecutive gaussians of the draw order): a lane takes four consecutive gaussians
+// (PACKED: one 16-B load of four packed rects), the wave sums its 256 counts with shuffles — no LDS, no barrier — and a workgroup
+// covers four emit blocks.  (Round 1-3: one workgroup per emit block with a block scan, 13 K workgroups of almost no work each:
+// 15 us for 13 MB; this form: 4x fewer workgroups, nothing to wait for.)
+constexpr int COUNT_BLOCKS_PER_WG = EMIT_THREADS / 64;  // emit blocks per count workgroup
+static_assert(EMIT_THREADS == 256, "a lane of the count kernel takes EMIT_THREADS / 64 = 4 gaussians: one uint4 of packed rects");
 template <bool PACKED, bool COARSE>
 __global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t *__restrict__ id_a, const uint32_t *__restrict__ id_b,
                                                                   const uint32_t *__restrict__ r8_a, const uint32_t *__restrict__ r8_b,
                                                                   const FrameCtrl *ctrl, const ushort4 *__restrict__ rect, Shard sh,
                                                                   uint32_t *__restrict__ blk_sum, uint2 *__restrict__ ranges,
                                                                   int n_tiles, uint32_t draw_limit, uint2 *__restrict__ cranges, int n_ctiles,
-                                                                  FrameCtrl *ctrl_w, uint32_t ent_off)
+                                                                  FrameCtrl *ctrl_w, uint32_t ent_off, int nblk_n)
 {
-    __shared__ uint32_t scratch[8];
     const uint32_t n = ctrl->n_visible;
+    const uint32_t t = blockIdx.x * EMIT_THREADS + threadIdx.x;
+    // threads in the grid (not gridDim.x: that would pull in the hidden kernarg block)
+    const uint32_t stride = (uint32_t)((nblk_n + COUNT_BLOCKS_PER_WG - 1) / COUNT_BLOCKS_PER_WG) * EMIT_THREADS;
     if (COARSE) {  // the cell ranges are rebuilt every frame too, and the expansion totals E with atomics
-        const uint32_t t = blockIdx.x * EMIT_THREADS + threadIdx.x;
-        if (t < (uint32_t)n_ctiles) cranges[t] = make_uint2(0u, 0u);
+        for (uint32_t c = t; c < (uint32_t)n_ctiles; c += stride) cranges[c] = make_uint2(0u, 0u);
         if (t == 0) { ctrl_w->n_pairs = 0u; ctrl_w->ent_off = ent_off; }
     }
+    for (uint32_t c = t; c < (uint32_t)n_tiles; c += stride) ranges[c] = make_uint2(0u, 0u);  // tile ranges are rebuilt every frame
     const bool odd = (ctrl->sort_passes & 1u) != 0;
     const uint32_t *sorted_ids = odd ? id_b : id_a, *sorted_rect8 = odd ? r8_b : r8_a;
-    const uint32_t r = blockIdx.x * EMIT_THREADS + threadIdx.x;
-    if (r < (uint32_t)n_tiles) ranges[r] = make_uint2(0u, 0u);  // tile ranges are rebuilt every frame
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t blk = blockIdx.x * COUNT_BLOCKS_PER_WG + (uint32_t)wave;  // this wave's emit block
+    if (blk >= (uint32_t)nblk_n) return;                                     // wave-uniform
+    const uint32_t r0 = blk * EMIT_THREADS + (uint32_t)lane * 4u;            // r = rank in the draw order
+    const uint32_t lim = n < draw_limit ? n : draw_limit;
     uint32_t cnt = 0;
-    if (r < n && r < draw_limit) {  // r = rank in the draw order
+    if (r0 < lim) {
         int first;
-        cnt = tiles_of(rect_of<PACKED, COARSE>(r, sorted_ids, sorted_rect8, rect), sh, &first);
+        if (PACKED && r0 + 4 <= lim) {  // the packed rects ride through the depth sort: four of them in one 16-B load (r0 is a multiple of 4)
+            const uint4 p4 = *reinterpret_cast<const uint4 *>(sorted_rect8 + r0);
+            const uint32_t p[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const ushort4 rc = unpack_rect8(p[j]);
+                cnt += tiles_of(COARSE ? coarse_rect(rc) : rc, sh, &first);
+            }
+        } else {
+            for (uint32_t r = r0; r < r0 + 4 && r < lim; ++r) cnt += tiles_of(rect_of<PACKED, COARSE>(r, sorted_ids, sorted_rect8, rect), sh, &first);
+        }
     }
-    uint32_t total;
-    block_excl_scan_256(cnt, scratch, &total);
-    if (threadIdx.x == 0) blk_sum[blockIdx.x] = total;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d, 64);
+    if (lane == 0) blk_sum[blk] = cnt;
 }
 
 // Single workgroup (1024 threads): exclusive scan of blk_sum[0..nblk) in place; totals into ctrl.  Sixteen
@@ -199,6 +220,9 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(uint32_t *__restrict__ 
 // Load-balanced expansion in emission order: a workgroup owns 256 consecutive gaussians and the contiguous slot range
 // their pairs occupy; every thread takes slots j, j+256, ..., finds the owning gaussian by binary search over the
 // workgroup's 256 offsets in LDS and writes (tile key, gaussian id) — coalesced stores however heavy-tailed the rects are.
+// (Round 4 measured the obvious refinement — gaussians of up to four cells, most of them, write their own pairs without search or
+// division, only the larger rects are load-balanced: 46.6 us either way.  The kernel is 13 K workgroups of a ~7-us dependent
+// chain each — counters, ids and rects, scan, stores — eight to a CU: six rounds of latency, not search or store throughput.)
 template <bool PACKED, bool COARSE>
 __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t *__restrict__ id_a, const uint32_t *__restrict__ id_b,
                                                                  const uint32_t *__restrict__ r8_a, const uint32_t *__restrict__ r8_b,
@@ -216,6 +240,9 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
     __shared__ float4 s_q0[EMIT_THREADS];
     __shared__ float4 s_q1[EMIT_THREADS];
     __shared__ uint32_t s_fine[COARSE ? EMIT_THREADS : 1];  // coarse: the gaussian's packed TILE rect
+    // the workgroup's slot base first: its load is independent of everything below and would otherwise wait behind two barriers
+    // (saturated at 2^32 - 1 by the scan: then nothing below is written)
+    const unsigned long long base = blk_off[blockIdx.x];
     const uint32_t n = ctrl->n_visible;
     const bool odd = (ctrl->sort_passes & 1u) != 0;
     const uint32_t *sorted_ids = odd ? id_b : id_a, *sorted_rect8 = odd ? r8_b : r8_a;
@@ -240,7 +267,6 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
     s_first[tid] = test ? -1 - first : first;
     __syncthreads();
 
-    const unsigned long long base = blk_off[blockIdx.x];  // saturated at 2^32 - 1 by the scan: then nothing below is written
     const uint32_t culled_row = (uint32_t)tiles_y << bits_x;
     uint32_t entries = 0;  // coarse: (gaussian, 16x16 tile) entries of the pairs this thread wrote = bits of their tile masks
     for (uint32_t j = tid; j < total; j += EMIT_THREADS) {
@@ -380,12 +406,12 @@ int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s)
     const int n_ctiles = ws.ctiles_x * ws.ctiles_y;
     const uint32_t cap = (uint32_t)ws.max_pairs;
     const uint32_t limit = opts.draw_limit > 0 ? (uint32_t)opts.draw_limit : 0xFFFFFFFFu;
-    // the count kernel also zeroes ranges[]: make sure its grid covers them
-    const int nblk = (int)((std::max<int64_t>(ws.n, n_tiles) + EMIT_THREADS - 1) / EMIT_THREADS);
-    const int nblk_n = (int)((ws.n + EMIT_THREADS - 1) / EMIT_THREADS);
-#define GSR_COUNT(P, C) hipLaunchKernelGGL((pair_count_kernel<P, C>), dim3(nblk), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
+    const int nblk_n = (int)((ws.n + EMIT_THREADS - 1) / EMIT_THREADS);                       // emit blocks (the bound: n >= V)
+    const int nblk_count = (nblk_n + COUNT_BLOCKS_PER_WG - 1) / COUNT_BLOCKS_PER_WG;          // the count kernel: one wave per emit block
+                                                                                              // (it also zeroes ranges[] / cranges[], grid-stride)
+#define GSR_COUNT(P, C) hipLaunchKernelGGL((pair_count_kernel<P, C>), dim3(nblk_count), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
                                            ws.ctrl, ws.rect, C ? csh : sh, ws.blk_sum, ws.ranges, n_tiles, limit, ws.cranges, n_ctiles, ws.ctrl, \
-                                           C ? (uint32_t)(reinterpret_cast<const char *>(ws.blk_sum) - reinterpret_cast<const char *>(ws.ctrl)) : 0u)
+                                           C ? (uint32_t)(reinterpret_cast<const char *>(ws.blk_sum) - reinterpret_cast<const char *>(ws.ctrl)) : 0u, nblk_n)
 #define GSR_EMIT(P, C) hipLaunchKernelGGL((pair_emit_kernel<P, C>), dim3(nblk_n), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
                                           ws.ctrl, ws.rect, C ? csh : sh, tk.bits_x, tk.grid_y, ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0], limit, \
                                           sh, ws.blk_sum)
