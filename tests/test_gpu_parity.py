@@ -395,6 +395,28 @@ def test_deferred_colour_is_exact(G):
     assert torch.equal(R.render_batch(cams), R.render_batch(cams, mk(colour_stage=1)))
 
 
+def test_launch_order_hint_changes_no_bit(G):
+    """blend.hip, tile_order_kernel: tiles are launched heaviest first by what each staged in the LAST frame rendered on the
+    workspace (GsrOptions.no_order_hint = 1: by list length).  A schedule only: the same bits after a frame of the same view, of
+    another view, of another frame size's leftovers (a re-carved workspace holds anything) and in a workspace filled with 0xFF."""
+    mk = G.renderer.make_options
+    cols, cam, _ = _medium(G, n=250_000, shift=1.4, W=960, H=540, pose=4)
+    other = _medium(G, n=10, W=960, H=540, pose=15)[1]
+    small = _medium(G, n=10, W=640, H=360, pose=2)[1]
+    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
+    ref = R.render(cam, mk(no_order_hint=True)).clone()
+    st = dict(R.last_stats)
+    assert torch.equal(R.render(cam), ref)                      # hint: the same view
+    R.render(other)
+    assert torch.equal(R.render(cam), ref)                      # hint: another view's work
+    R.render(small)
+    assert torch.equal(R.render(cam), ref)                      # another frame size in between: the workspace is carved anew
+    R._workspace(cam.width, cam.height).fill_(255)
+    R._chained = False
+    assert torch.equal(R.render(cam), ref)                      # garbage where the hint lives
+    assert all(R.last_stats[k] == st[k] for k in st if k != "colour_evals")
+
+
 def test_early_out_is_a_bounded_approximation(G):
     cols, cam, _ = _medium(G)
     R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
