@@ -486,7 +486,7 @@ def test_three_phase_shard_preprocess_on_its_other_paths(G):
     """preprocess.hip: ranks of 5+ shards find their gaussians with shard_preprocess_kernel (bound -> geometry -> colour, runs
     compacted for the depth sort).  test_tile_row_shards_reassemble_bit_exactly covers it at step 8 on the packed-rect fp32
     path; here the remaining instantiations, all bit for bit against the whole frame: fp16 SH storage, a frame wider than
-    256 tiles (rects gathered by id, no packed payload through the sort), GSR_SHARD_PREPROCESS-independent debug outputs
+    256 tiles (rects gathered by id, no packed payload through the sort), debug outputs that do not depend on the shard's path
     (a debug call on a shard still fills every gaussian's intermediates, then renders the shard correctly)."""
     mk = G.renderer.make_options
 
@@ -520,6 +520,12 @@ def test_three_phase_shard_preprocess_on_its_other_paths(G):
     for k in whole:
         assert torch.equal(whole[k], shard[k]), k
     assert torch.equal(R.render(cam, o8), strip)
+    # GsrOptions.shard_preprocess forces either kernel for any step: the same strip from both, also where the default picks the other
+    for step, r in ((3, 1), (8, 5), (2, 0)):
+        so = dict(tile_row_begin=r, tile_row_step=step, output_layout=2)
+        a, b = R.render(cam, mk(shard_preprocess=1, **so)), R.render(cam, mk(shard_preprocess=2, **so))
+        assert torch.equal(a, b) and torch.equal(a, R.render(cam, mk(**so))) and bool(a.any()), (step, r)
+        assert torch.equal(R.render(cam, mk(shard_preprocess=2, colour_stage=1, **so)), a)
 
 
 def test_full_hd_one_million(G):
