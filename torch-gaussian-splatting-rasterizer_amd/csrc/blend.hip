@@ -6,7 +6,9 @@
 //
 // Per tile list (depth-ordered by the two radix sorts):
 //   - 128 (256) entries at a time are staged in LDS: each thread gathers one 48-B record (3 x 16-B loads)
-//     addressed by the list entry, so HBM/L2 sees 16-B vector loads and the list itself is read coalesced;
+//     addressed by the list entry, so HBM/L2 sees 16-B vector loads and the list itself is read coalesced; a record whose colour
+//     nobody has evaluated yet gets it here (staged_q2: sh_to_rgb, spherical_harmonics.py:27-73, when a tile first stages the
+//     gaussian — most gaussians of a dense scene are never staged by anyone);
 //   - footprint.h decides, 64 entries per instruction, whether an entry can touch the wave's quadrant(s); the wave
 //     walks only the surviving bits of the ballot (scalar loop, no divergence);
 //   - per pixel the reference's arithmetic: power (log2 domain, coefficients pre-scaled in preprocess),
@@ -21,15 +23,16 @@
 // Two kernels share this: blend_kernel, the plain-C statement (blend_impl = 1), and blend_walk_kernel, the product, whose
 // inner walk is one hand-scheduled asm statement — bit-identical frames (its comment has the measurements).
 //
-// Launch order: list lengths are heavy-tailed (longest ~3.5x the mean) and a frame is only ~4 rounds of
-// resident workgroups, so tiles are launched longest-first (tile_order_kernel: per XCD group, bucketed by
-// length).  XCD k (workgroups b with b % 8 == k) takes the tile rows k, k+8, ...: x-neighbours, which share
+// Launch order: a tile's work is heavy-tailed and a frame is only ~2 rounds of resident workgroups, so tiles are launched
+// heaviest-first (tile_order_kernel: per XCD group, bucketed by what the tile's blend staged in the last frame on this workspace,
+// by list length where that is unknown).  XCD k (workgroups b with b % 8 == k) takes the tile rows k, k+8, ...: x-neighbours, which share
 // most of their gaussians, hit the same L2, and heavy image regions are spread over all XCDs.
 //
 // Roofline: algorithmic bytes = 40 per consumed entry (4 id + 36 record) + 12 per pixel
-// + 8 per tile range.  The kernel is bound on-chip, not by HBM: per evaluated (quadrant, entry) ~15 VALU issues incl. one
-// quarter-rate v_exp_f32, and the record's three wave-wide LDS broadcast reads (10 LDS cycles).  bench.py reports the HBM
-// fraction (the contract figure) and, from the committed PMC passes, the VALU issue and LDS busy fractions.
+// + 8 per tile range + 216 per colour evaluated here (the 192-B SH row, the mean, the write-back).  The kernel is bound on-chip, not
+// by HBM: per evaluated (quadrant, entry) ~15 VALU issues incl. one quarter-rate v_exp_f32, and the record's three wave-wide LDS
+// broadcast reads (10 LDS cycles); since the colour-saturation rule also by its heaviest tiles.  bench.py reports the HBM fraction
+// (the contract figure) and, from the committed PMC passes, the VALU issue and LDS busy fractions.
 #include "gsr_internal.h"
 #include "blend_args.h"
 #include "footprint.h"

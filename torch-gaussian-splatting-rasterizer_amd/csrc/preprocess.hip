@@ -7,9 +7,9 @@
 // tile rect, det == 0) see the same values the reference sees, up to libm-vs-ocml differences in
 // expf (<= 1 ulp).
 //
-// Roofline: HBM.  Algorithmic bytes per gaussian: 236 read (xyz 12, scale 12, rot 16, opacity 4,
-// SH 192) + 52..64 written per visible gaussian.  Culled / off-screen gaussians
-// leave before the SH read.
+// Roofline: HBM.  Algorithmic bytes per gaussian: 44 read (xyz 12, scale 12, rot 16, opacity 4) + 52..64 written per visible
+// gaussian; the 192-B SH row only with GsrOptions.colour_stage = 1 — by default the blend evaluates a
+// gaussian's colour when a tile first stages it (blend.hip), and most gaussians of a dense scene are never staged.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
