@@ -26,7 +26,8 @@ extern "C" {
 #endif
 
 #define GSR_VERSION 500 /* 0.5.0: GsrOptions.saturation_rule (the exact colour-saturation early-out), the four environment switches became GsrOptions
-                            fields (the library reads no environment and holds no function statics), + gsr_scene_order.  0.4.0: GsrOptions.keep_flags, GsrOptions.accum_dtype; GsrStats.sort_passes reports the worst frame when the bound was exceeded; blend_impl 2
+                            fields (the library reads no environment and holds no function statics), GsrOptions.colour_stage / no_order_hint,
+                            GsrStats.colour_evals.  0.4.0: GsrOptions.keep_flags, GsrOptions.accum_dtype; GsrStats.sort_passes reports the worst frame when the bound was exceeded; blend_impl 2
                             (matrix-pipe experiment) removed; the frame clear covers every word of the control block.  0.3.0: GsrOptions.depth_sort_passes, GsrStats.sort_passes, GSR_ERR_SORT_PASSES.  0.2.1: + gsr_render_batch_slots.
                             0.2.0: gsr_preprocess_geometry/_color removed (measured slower), gsr_read_stats takes a non-const workspace */
 
