@@ -124,14 +124,15 @@ class GaussianScene:
         """Reorder the resident arrays along the Morton curve of the means (on the device; a scene already ordered is left alone)."""
         if self.order_t is not None or self.n == 0:
             return self
-        t0 = torch.cuda.Event(enable_timing=True)
-        t1 = torch.cuda.Event(enable_timing=True)
-        t0.record()
-        order = morton_order_device(self.t["means"])
-        for k in self.FIELDS:
-            self.t[k] = self.t[k].index_select(0, order).contiguous()
-        t1.record()
-        t1.synchronize()
+        with torch.cuda.device(self.device):  # the events (and the sorts' temporaries) belong to the scene's device, whichever is current
+            t0 = torch.cuda.Event(enable_timing=True)
+            t1 = torch.cuda.Event(enable_timing=True)
+            t0.record()
+            order = morton_order_device(self.t["means"])
+            for k in self.FIELDS:
+                self.t[k] = self.t[k].index_select(0, order).contiguous()
+            t1.record()
+            t1.synchronize()
         self.order_t, self._order_np, self.order_ms = order, None, float(t0.elapsed_time(t1))
         return self
 
