@@ -27,7 +27,7 @@ extern "C" {
 
 #define GSR_VERSION 500 /* 0.5.0: GsrOptions.saturation_rule (the exact colour-saturation early-out), the four environment switches became GsrOptions
                             fields (the library reads no environment and holds no function statics), GsrOptions.colour_stage / no_order_hint,
-                            GsrStats.colour_evals.  0.4.0: GsrOptions.keep_flags, GsrOptions.accum_dtype; GsrStats.sort_passes reports the worst frame when the bound was exceeded; blend_impl 2
+                            GsrStats.colour_evals, + gsr_scene_order.  0.4.0: GsrOptions.keep_flags, GsrOptions.accum_dtype; GsrStats.sort_passes reports the worst frame when the bound was exceeded; blend_impl 2
                             (matrix-pipe experiment) removed; the frame clear covers every word of the control block.  0.3.0: GsrOptions.depth_sort_passes, GsrStats.sort_passes, GSR_ERR_SORT_PASSES.  0.2.1: + gsr_render_batch_slots.
                             0.2.0: gsr_preprocess_geometry/_color removed (measured slower), gsr_read_stats takes a non-const workspace */
 
@@ -244,6 +244,16 @@ int gsr_render_batch_slots(const GsrScene *scene, const GsrCamera *cams /* [host
  * data changes), copies the frame counters to host memory and waits for the stream.
  * Returns GSR_ERR_PAIR_OVERFLOW if the frame overflowed max_pairs, GSR_ERR_SORT_PASSES if depth_sort_passes was too small. */
 int gsr_read_stats(void *workspace, size_t workspace_bytes, GsrStats *out /* [host] */, void *stream);
+
+/* Scene order (no reference counterpart: the reference reads the .ply in file order, rasterize.py:353-358, and its result does not
+ * depend on the storage order except for gaussians at exactly equal depth, which its unstable torch.sort leaves undefined and this
+ * library draws in array-index order).  perm_out[i] = index, in the caller's arrays, of the gaussian that should be stored i-th: the
+ * gaussians along a Morton curve of their means (every axis rank-quantised to 10 bits, bits interleaved, stable).  Gathering all five
+ * scene arrays with it before rendering makes the same frames ~10 % faster on MI355X (culled waves, L2 hits).  Once per scene:
+ * sixteen radix passes, ~2 ms at 6 M gaussians.  workspace: gsr_scene_order_bytes(n) bytes, 256-B aligned, free afterwards. */
+int gsr_scene_order_bytes(int64_t n, size_t *bytes /* [host] */);
+int gsr_scene_order(int64_t n, const float *means /* [n,3] */, uint32_t *perm_out /* [n] */, void *workspace, size_t workspace_bytes,
+                    void *stream);
 
 /* Stand-alone helpers behind the reference's helper functions (same maths as inside gsr_preprocess). */
 /* sh_to_rgb, spherical_harmonics.py:27-73 */

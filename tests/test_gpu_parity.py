@@ -868,7 +868,18 @@ def test_spatial_order_renders_the_same_frame(G):
     plain = G.renderer.Rasterizer(plain_scene)
     scene = G.renderer.GaussianScene.from_packed(packed)
     assert sorted(scene.order.tolist()) == list(range(150_000)) and not np.array_equal(scene.order, np.arange(150_000))
-    assert np.array_equal(scene.order, G.renderer.morton_order(packed["means"]))      # device sorts == the numpy statement
+    assert np.array_equal(scene.order, G.renderer.morton_order(packed["means"]))      # gsr_scene_order == the numpy statement
+    # ... also with repeated coordinates, signed zeros and a count that fills no sort tile (stable ranks, -0.0 == +0.0)
+    rng = np.random.default_rng(11)
+    for n_ in (1, 2, 255, 4097, 70_001):
+        m_ = rng.normal(size=(n_, 3)).astype(np.float32)
+        m_[rng.integers(0, n_, n_ // 3)] = m_[rng.integers(0, n_, n_ // 3)]
+        m_[rng.integers(0, n_, max(1, n_ // 7)), rng.integers(0, 3)] = np.float32(-0.0)
+        m_[rng.integers(0, n_, max(1, n_ // 7)), rng.integers(0, 3)] = np.float32(0.0)
+        dev = torch.from_numpy(m_).cuda()
+        want = G.renderer.morton_order(m_)
+        assert np.array_equal(G.renderer.scene_order(dev).cpu().numpy(), want), n_
+        assert np.array_equal(G.renderer.morton_order_device(dev).cpu().numpy(), want), n_
     for k in scene.FIELDS:
         assert np.array_equal(scene.t[k].cpu().numpy(), packed[k][scene.order]), k
     assert scene.sort_spatially() is scene and scene.order_ms > 0

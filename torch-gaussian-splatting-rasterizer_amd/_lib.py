@@ -117,7 +117,7 @@ class GsrDebugOut(C.Structure):
 EXPORTS = [
     "gsr_version", "gsr_last_error", "gsr_default_options", "gsr_camera_setup", "gsr_workspace_bytes",
     "gsr_preprocess", "gsr_bin_sort", "gsr_blend", "gsr_render_forward", "gsr_read_stats", "gsr_sh_to_rgb", "gsr_cov3d",
-    "gsr_render_batch", "gsr_render_batch_slots", "gsr_project_to_camera_space", "gsr_compute_2d_covariance", "gsr_compute_covering_bbox", "gsr_rasterize_gaussian",
+    "gsr_render_batch", "gsr_render_batch_slots", "gsr_scene_order", "gsr_scene_order_bytes", "gsr_project_to_camera_space", "gsr_compute_2d_covariance", "gsr_compute_covering_bbox", "gsr_rasterize_gaussian",
 ]
 
 
@@ -145,6 +145,8 @@ def _load() -> C.CDLL:
     L.gsr_render_batch_slots.argtypes = [C.POINTER(GsrScene), C.POINTER(GsrCamera), i32, C.POINTER(GsrOptions), i64, C.POINTER(vp), sz,
                                          C.POINTER(vp), i32, vp, i64]
     L.gsr_read_stats.argtypes = [vp, sz, C.POINTER(GsrStats), vp]
+    L.gsr_scene_order_bytes.argtypes = [i64, C.POINTER(sz)]
+    L.gsr_scene_order.argtypes = [i64, vp, vp, vp, sz, vp]
     L.gsr_sh_to_rgb.argtypes = [i64, vp, vp, C.POINTER(C.c_float), i32, vp, vp]
     L.gsr_cov3d.argtypes = [i64, vp, vp, vp, vp]
     f16 = C.POINTER(C.c_float)

@@ -368,6 +368,24 @@ int gsr_read_stats(void *workspace, size_t workspace_bytes, GsrStats *out, void 
     return GSR_OK;
 }
 
+int gsr_scene_order_bytes(int64_t n, size_t *bytes)
+{
+    if (!bytes || n < 0 || n > 0x7FFFFFFF) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
+    *bytes = scene_order_bytes(n);
+    return GSR_OK;
+}
+
+int gsr_scene_order(int64_t n, const float *means, uint32_t *perm_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (n < 0 || n > 0x7FFFFFFF || (n > 0 && (!means || !perm_out || !workspace))) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
+    if (n > 0 && reinterpret_cast<uintptr_t>(workspace) % 256 != 0) { set_error("workspace must be 256-byte aligned"); return GSR_ERR_BAD_ARG; }
+    if (workspace_bytes < scene_order_bytes(n)) {
+        set_error("workspace too small: %zu bytes given, %zu needed", workspace_bytes, scene_order_bytes(n));
+        return GSR_ERR_WORKSPACE;
+    }
+    return launch_scene_order(n, means, perm_out, workspace, static_cast<hipStream_t>(stream));
+}
+
 int gsr_sh_to_rgb(int64_t n, const float *means, const float *sh, const float cam_center[3], int32_t degree, float *rgb_out,
                   void *stream)
 {

@@ -124,6 +124,9 @@ int launch_rasterize_gaussian(int64_t g, const int64_t *bboxes, float *screen, c
 // rects) in val[p] / rect8[p], p = FrameCtrl.sort_passes & 1 (decided on the device from the frame's key range).  passes: how
 // many to enqueue (GsrOptions.depth_sort_passes; 0 = 4).
 int launch_depth_sort(const Workspace &ws, bool packed_rect, bool compact_input, int passes, hipStream_t s);
+// gsr_scene_order (sort.hip): Morton-curve permutation of the gaussians, built with the radix passes of the pair sort
+size_t scene_order_bytes(int64_t n);
+int launch_scene_order(int64_t n, const float *means, uint32_t *perm_out, void *workspace, hipStream_t s);
 // Stable radix sort of the pair arrays over key bits [first_bit, key_bits); the first pass drops keys >= drop_from and leaves the
 // survivor count in *n_out.  in_buf / *result_buf: which of pkey[]/pval[] holds input / output.
 int launch_pair_sort(const Workspace &ws, int in_buf, const uint32_t *n_dev, int first_bit, int key_bits, uint32_t drop_from,

@@ -52,10 +52,28 @@ def morton_order(means: np.ndarray) -> np.ndarray:
     return np.argsort(code, kind="stable")
 
 
+def scene_order(means: torch.Tensor) -> torch.Tensor:
+    """morton_order through the C ABI (gsr_scene_order: libgsr's own radix passes, ~2 ms at 6 M gaussians, no first-use kernel
+    loading): int64 permutation on the device of `means`, element for element the numpy statement's."""
+    _require_cuda(means, "means")
+    n = int(means.shape[0])
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int64, device=means.device)
+    m = means.contiguous().float()
+    need = C.c_size_t(0)
+    check(lib.gsr_scene_order_bytes(n, C.byref(need)))
+    with torch.cuda.device(means.device):
+        ws = torch.empty(int(need.value), dtype=torch.uint8, device=means.device)
+        perm = torch.empty(n, dtype=torch.int32, device=means.device)  # uint32 on the wire; n < 2^31
+        check(lib.gsr_scene_order(n, m.data_ptr(), perm.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(means.device)))
+        return perm.to(torch.int64)
+
+
 def morton_order_device(means: torch.Tensor) -> torch.Tensor:
-    """morton_order on the device the means live on (the loaders' path: ~5 s of numpy for 6 M gaussians became a few sorts on the
-    GPU at upload, off the render path): the same permutation, element for element — per axis a stable argsort and its inverse give
-    the ranks, the quantised ranks are interleaved into 30-bit codes, one more stable argsort orders them."""
+    """morton_order with torch ops, on whatever device the means live on (CPU in the tests): the same permutation, element for
+    element — per axis a stable argsort and its inverse give the ranks, the quantised ranks are interleaved into 30-bit codes, one
+    more stable argsort orders them.  On the GPU the loaders use `scene_order` (the C ABI) instead: the first torch sort of a
+    process costs 0.1-0.4 s of rocPRIM kernel loading."""
     n = int(means.shape[0])
     if n == 0:
         return torch.zeros(0, dtype=torch.int64, device=means.device)
@@ -128,7 +146,7 @@ class GaussianScene:
             t0 = torch.cuda.Event(enable_timing=True)
             t1 = torch.cuda.Event(enable_timing=True)
             t0.record()
-            order = morton_order_device(self.t["means"])
+            order = scene_order(self.t["means"])
             for k in self.FIELDS:
                 self.t[k] = self.t[k].index_select(0, order).contiguous()
             t1.record()
