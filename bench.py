@@ -207,7 +207,7 @@ def stage_profile(R, scene, cam, opts, out_shape, tiles, reps, sh_half, prof, de
         e[1].record(stream)
         check(lib.gsr_bin_sort(n, C.byref(cam), C.byref(opts), R.max_pairs, ws.data_ptr(), ws.numel(), sp))
         e[2].record(stream)
-        check(lib.gsr_blend(n, C.byref(cam), C.byref(opts), R.max_pairs, ws.data_ptr(), ws.numel(), out.data_ptr(), None, sp))
+        check(lib.gsr_blend(C.byref(sc), n, C.byref(cam), C.byref(opts), R.max_pairs, ws.data_ptr(), ws.numel(), out.data_ptr(), None, sp))
         e[3].record(stream)
     torch.cuda.synchronize(dev)
     st = R.stats()

@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 500 /* 0.5.0: GsrOptions.saturation_rule (the exact colour-saturation early-out), the four environment switches became GsrOptions
+#define GSR_VERSION 600 /* 0.6.0: several views per launch sequence — gsr_render_batch / gsr_render_batch_slots put as many views through ONE
+                            preprocess / sort / blend launch sequence as the workspace holds slices of gsr_workspace_bytes() (GsrOptions.batch_views
+                            caps it); gsr_blend takes the scene again (NULL = what gsr_preprocess left in the workspace).  0.5.0: GsrOptions.saturation_rule (the exact colour-saturation early-out), the four environment switches became GsrOptions
                             fields (the library reads no environment and holds no function statics), GsrOptions.colour_stage / no_order_hint,
                             GsrStats.colour_evals, + gsr_scene_order.  0.4.0: GsrOptions.keep_flags, GsrOptions.accum_dtype; GsrStats.sort_passes reports the worst frame when the bound was exceeded; blend_impl 2
                             (matrix-pipe experiment) removed; the frame clear covers every word of the control block.  0.3.0: GsrOptions.depth_sort_passes, GsrStats.sort_passes, GSR_ERR_SORT_PASSES.  0.2.1: + gsr_render_batch_slots.
@@ -50,6 +52,7 @@ typedef enum GsrStatus {
 #define GSR_LOWPASS 0.3f             /* rasterize.py:249-250 */
 #define GSR_EIG_FLOOR 0.1f           /* rasterize.py:172,175 */
 #define GSR_MAX_PAIRS 0xFFFFE000ll   /* largest max_pairs: pairs are indexed in 32 bits, one 4096-pair sort tile of headroom */
+#define GSR_MAX_BATCH_VIEWS 8        /* most views gsr_render_batch puts through one launch sequence */
 
 /* Camera-independent trained gaussians, exactly the values stored in the INRIA .ply
  * (rasterize.py:98-106,354-358; utils.py:10-31).  Row-major dense arrays. */
@@ -147,6 +150,9 @@ typedef struct GsrOptions {
                                  gsr_preprocess reads this field; gsr_blend finds out from the records. */
     int32_t sh_dense_min;     /* visible gaussians per wave from which the preprocess fetches the wave's 64 SH rows whole through LDS:
                                  0 (default) = 48, 65 = never (csrc/preprocess.hip).  Was GSR_SH_DENSE. */
+    int32_t batch_views;      /* gsr_render_batch / gsr_render_batch_slots: at most this many views per launch sequence; 0 (default) = as many
+                                 as the workspace holds slices for, up to GSR_MAX_BATCH_VIEWS.  1 = one view at a time (rounds 1-4).  Same
+                                 frames whatever it says. */
 } GsrOptions;
 
 /* Counters of one frame (device -> host with gsr_read_stats). */
@@ -212,20 +218,29 @@ int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_
  * and :255-305 (rasterize_gaussian).  out_image layout per opts->output_layout; out_final_T [H,W] may be NULL.
  * n and max_pairs must be the values given to the earlier stages (the library keeps no state; they fix the
  * workspace layout).  With GsrOptions.colour_stage = 0 (default) this stage evaluates sh_to_rgb (spherical_harmonics.py:27-73) for
- * the gaussians its tiles stage: it reads the scene's `means` and `sh` arrays through the pointers gsr_preprocess left in the
- * workspace, so those arrays must still be alive and unchanged. */
-int gsr_blend(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs, void *workspace,
-              size_t workspace_bytes, void *out_image /* float32 or bfloat16, opts->output_dtype */, float *out_final_T,
-              void *stream);
+ * the gaussians its tiles stage, from `scene`'s means / sh arrays and cam->cam_center: pass the scene gsr_preprocess was given
+ * (the same values: the arrays may have MOVED since, they may not have changed).  scene = NULL: the pointers gsr_preprocess left
+ * in the workspace are used instead — then those arrays must still be alive where they were, which no argument check can see
+ * (a binding should always pass the scene). */
+int gsr_blend(const GsrScene *scene /* may be NULL */, int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,
+              void *workspace, size_t workspace_bytes, void *out_image /* float32 or bfloat16, opts->output_dtype */,
+              float *out_final_T, void *stream);
 
 /* Stages 1-3 back to back: the whole render call of rasterize.py:354-446. */
 int gsr_render_forward(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,
                        void *workspace, size_t workspace_bytes, void *out_image, float *out_final_T, void *stream);
 
-/* Several views of ONE resident scene, enqueued back to back on the stream with one workspace (the reference renders
- * one view per process, rasterize.py:315-329).  cams[n_cams] [host] must share width/height; frame i goes to
- * out_images + i * frame_stride (in elements of the output dtype).  Counters afterwards describe the LAST view; an overflow in any view is
- * sticky in them, and n_pairs_bbox / sort_passes then report what the WORST view needed (the values to re-render with). */
+/* Several views of ONE resident scene (the reference renders one view per process, rasterize.py:315-329; BASELINE configs[3] is a
+ * camera set).  cams[n_cams] [host] must share width/height; frame i goes to out_images + i * frame_stride (in elements of the
+ * output dtype).
+ * Views per launch sequence.  With S = gsr_workspace_bytes(n, width, height, max_pairs), a workspace of K * S bytes is K slices,
+ * and K = min(workspace_bytes / S, GSR_MAX_BATCH_VIEWS, opts->batch_views if set, n_cams) views at a time go through ONE sequence
+ * of launches — one preprocess that reads every gaussian's 44 B once for the K cameras, one set of depth-sort and cell-sort launches
+ * over K x the keys, one blend over K x the tiles: ~22 dispatches per K frames instead of per frame, each K times better filled.
+ * View i works in slice i % K (workspace + (i % K) * S) and its frame is bit for bit the frame gsr_render_forward renders.
+ * Counters: gsr_read_stats on slice j (pointer workspace + j * S, size S) describes the LAST view rendered there (views j, j + K, ...);
+ * an overflow in any of them is sticky in it, and n_pairs_bbox / sort_passes then report what the WORST of them needed (the values
+ * to re-render with).  A caller that checks a batch reads slices 0 .. min(K, n_cams) - 1. */
 int gsr_render_batch(const GsrScene *scene, const GsrCamera *cams /* [host] */, int32_t n_cams, const GsrOptions *opts,
                      int64_t max_pairs, void *workspace, size_t workspace_bytes, void *out_images, int64_t frame_stride,
                      void *stream);

@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} declared in include/gsr.h but not exported by libgsr.so"
     assert sorted(_lib.EXPORTS) == names
-    assert _lib.lib.gsr_version() == 500
+    assert _lib.lib.gsr_version() == 600
 
 
 def test_struct_sizes_match_header():
@@ -31,7 +31,7 @@ def test_struct_sizes_match_header():
 
     assert C.sizeof(_lib.GsrScene) == 56
     assert C.sizeof(_lib.GsrCamera) == 4 * (16 + 16 + 3 + 6) + 8
-    assert C.sizeof(_lib.GsrOptions) == 76 and _lib.GsrOptions.keep_flags.offset == 44 and _lib.GsrOptions.accum_dtype.offset == 40
+    assert C.sizeof(_lib.GsrOptions) == 80 and _lib.GsrOptions.batch_views.offset == 76 and _lib.GsrOptions.keep_flags.offset == 44 and _lib.GsrOptions.accum_dtype.offset == 40
     assert _lib.GsrOptions.saturation_rule.offset == 48 and _lib.GsrOptions.sh_dense_min.offset == 72 and _lib.GsrOptions.colour_stage.offset == 68 and _lib.GsrOptions.no_order_hint.offset == 64
     assert C.sizeof(_lib.GsrStats) == 48 and _lib.GsrStats.colour_evals.offset == 40 and _lib.GsrStats.wave_entries.offset == 24 and _lib.GsrStats.fetched_entries.offset == 32
     assert C.sizeof(_lib.GsrDebugOut) == 72
@@ -71,7 +71,7 @@ def test_gpu_entry_points_reject_bad_arguments_without_touching_a_gpu():
     sc.n = 10                                                    # null arrays
     assert _lib.lib.gsr_render_forward(C.byref(sc), C.byref(cam), C.byref(o), 100, None, 0, None, None, None) == _lib.GSR_ERR_BAD_ARG
     assert b"null" in _lib.lib.gsr_last_error()
-    assert _lib.lib.gsr_blend(0, C.byref(cam), C.byref(o), 0, None, 0, None, None, None) == _lib.GSR_ERR_BAD_ARG
+    assert _lib.lib.gsr_blend(None, 0, C.byref(cam), C.byref(o), 0, None, 0, None, None, None) == _lib.GSR_ERR_BAD_ARG
 
 
 def test_product_never_touches_the_oracle():

@@ -152,6 +152,68 @@ def test_multi_camera_batch(G):
     assert not torch.equal(singles[0], singles[1])
 
 
+def test_views_per_launch_sequence_render_the_single_view_frames(G):
+    """gsr_render_batch with a workspace of K slices: K views through ONE preprocess / sort / blend launch sequence (ABI 0.6.0).  The
+    same kernels on the same per-view values, so every frame must equal the single-view render bit for bit: K = 2, 3, 4, 8, batches
+    that do not fill their last group, GsrOptions.batch_views capping K, the overflow and depth-sort-bound recovery (the worst view
+    decides), colours in the preprocess, fp16 SH, fine binning, bf16 store, shards through both preprocess kernels, frames in flight."""
+    cols, cam0, _ = _medium(G, n=60_000)
+    W, H = cam0.width, cam0.height
+    fx = G.synthetic.pinhole_focal(W)
+    mk = G.renderer.make_options
+    cams = [G.renderer.make_camera(p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H) for p in G.synthetic.ring_cameras(25)[::3]]  # 9 views
+    scene = G.renderer.GaussianScene.from_columns(cols)
+    ref = G.renderer.Rasterizer(scene)
+    singles = torch.stack([ref.render(c) for c in cams])
+    need = ref.max_pairs
+    for K in (2, 3, 4, 8):
+        R = G.renderer.Rasterizer(scene, views=K)
+        assert torch.equal(R.render_batch(cams), singles), K
+        assert len(R.last_slice_stats) == min(K, len(cams))
+        # the counters of slice j are those of the last view it rendered: views j, j + K, ...
+        for j, st in enumerate(R.last_slice_stats):
+            last = max(i for i in range(len(cams)) if i % K == j)
+            ref.render(cams[last])
+            for k in ("n_visible", "n_pairs_bbox", "n_pairs", "sort_passes", "max_list_len"):  # (what the blend stages depends on its batch size)
+                assert st[k] == ref.last_stats[k], (K, j, k)
+        assert torch.equal(R.render_batch(cams[:K - 1]), singles[:K - 1])            # fewer views than slices
+        assert torch.equal(R.render_batch(cams, mk(batch_views=2)), singles)          # the option caps K
+        assert torch.equal(R.render(cams[1]), singles[1])                             # single frames on slice 0 of the same workspace
+    R = G.renderer.Rasterizer(scene, max_pairs=2048, views=4)                          # too small: an overflow in ANY view of ANY group must be caught
+    assert torch.equal(R.render_batch(cams), singles) and R.max_pairs > 2048
+    R = G.renderer.Rasterizer(scene, views=4)
+    R.sort_passes = 1                                                                 # a learned bound that is too small for these views
+    assert torch.equal(R.render_batch(cams), singles) and R.sort_passes >= 2
+    for kw in (dict(colour_stage=1), dict(fine_binning=True), dict(output_bf16=True), dict(blend_impl=1), dict(reference_compat=False),
+               dict(saturation_rule=1), dict(no_footprint_cull=True), dict(draw_limit=5000)):
+        one = torch.stack([ref.render(c, mk(**kw)) for c in cams[:5]])
+        assert torch.equal(G.renderer.Rasterizer(scene, views=4).render_batch(cams[:5], mk(**kw)), one), kw
+    half = G.renderer.GaussianScene.from_columns(cols, sh_half=True)
+    one = torch.stack([G.renderer.Rasterizer(half).render(c) for c in cams[:5]])
+    assert torch.equal(G.renderer.Rasterizer(half, views=4).render_batch(cams[:5]), one)
+    assert torch.equal(G.renderer.Rasterizer(half, views=4).render_batch(cams[:5], mk(colour_stage=1)), one)
+    # tile-row shards (a multi-GPU rank's frames): strips [B, rows * 16, W, 3]; step 2 goes through the whole-frame preprocess kernel,
+    # step 8 through the three-phase one
+    for begin, step in ((1, 2), (3, 8), (0, 5)):
+        o = mk(tile_row_begin=begin, tile_row_step=step, output_layout=2)
+        strips = torch.stack([ref.render(c, o) for c in cams])
+        R = G.renderer.Rasterizer(scene, views=4)
+        assert torch.equal(R.render_batch(cams, o), strips), (begin, step)
+    # frames in flight: each slot takes `views` consecutive cameras per launch sequence
+    fif = G.renderer.FramesInFlight(scene, slots=2, max_pairs=need, views=4)
+    assert torch.equal(fif.render_batch(cams), singles)
+    outs = torch.empty((2, 4, H, W, 3), device="cuda")
+    for rnd in range(2):
+        for g in range(2):
+            fif.submit_batch(cams[4 * g: 4 * g + 4], ref.bounded(mk()), out=outs[g])
+    fif.synchronize()
+    for g in range(2):
+        fif.stats(g)
+    assert torch.equal(outs.view(8, H, W, 3), singles[:8])
+    small = G.renderer.FramesInFlight(scene, slots=2, max_pairs=2048, views=3)
+    assert torch.equal(small.render_batch(cams), singles) and small.rasterizers[0].max_pairs > 2048
+
+
 def test_frames_in_flight_are_bit_identical_to_single_stream(G):
     """renderer.FramesInFlight / gsr_render_batch_slots: independent frames on separate HIP streams, one workspace each
     (bench.py's throughput mode).  Same kernels on the same inputs, so every frame must equal the single-stream render bit

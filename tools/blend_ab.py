@@ -50,7 +50,7 @@ def main():
             o = renderer.make_options(early_out_T=a.early_out_T, blend_impl=i)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            check(lib.gsr_blend(n, C.byref(cam), C.byref(o), R.max_pairs, ws.data_ptr(), ws.numel(), outs[i].data_ptr(), None, sp))
+            check(lib.gsr_blend(None, n, C.byref(cam), C.byref(o), R.max_pairs, ws.data_ptr(), ws.numel(), outs[i].data_ptr(), None, sp))
             e1.record(stream)
             torch.cuda.synchronize(dev)
             if rnd >= 2:

@@ -46,7 +46,7 @@ def main():
         for i in range(a.reps + 3):
             e = ev[max(i - 3, 0)]
             e[0].record()
-            check(lib.gsr_blend(n, C.byref(cam), C.byref(blend_opts), R.max_pairs, ws.data_ptr(), ws.numel(), out.data_ptr(), None, sp))
+            check(lib.gsr_blend(None, n, C.byref(cam), C.byref(blend_opts), R.max_pairs, ws.data_ptr(), ws.numel(), out.data_ptr(), None, sp))
             e[1].record()
         torch.cuda.synchronize()
         ms = float(np.median([x.elapsed_time(y) for x, y in ev]))

@@ -63,7 +63,7 @@ def main():
                 ev[1].record(stream)
                 check(lib.gsr_bin_sort(n, C.byref(cam), C.byref(opts), R.max_pairs, ws.data_ptr(), ws.numel(), sp))
                 ev[2].record(stream)
-                check(lib.gsr_blend(n, C.byref(cam), C.byref(opts), R.max_pairs, ws.data_ptr(), ws.numel(), outs[name].data_ptr(), None, sp))
+                check(lib.gsr_blend(None, n, C.byref(cam), C.byref(opts), R.max_pairs, ws.data_ptr(), ws.numel(), outs[name].data_ptr(), None, sp))
                 ev[3].record(stream)
             torch.cuda.synchronize(dev)
             if rnd >= 2:

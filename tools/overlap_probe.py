@@ -32,7 +32,7 @@ torch.cuda.synchronize()
 
 def blend(k):
     for _ in range(k):
-        check(lib.gsr_blend(n, C.byref(cam), C.byref(opts), R.max_pairs, ws.data_ptr(), ws.numel(), out.data_ptr(), None, sa.cuda_stream))
+        check(lib.gsr_blend(None, n, C.byref(cam), C.byref(opts), R.max_pairs, ws.data_ptr(), ws.numel(), out.data_ptr(), None, sa.cuda_stream))
 def copy(k):
     with torch.cuda.stream(sb):
         for _ in range(k):

@@ -59,7 +59,7 @@ for NW in [int(x) for x in (sys.argv[1:] or ["2", "3", "4"])]:
                 sorted_ev[k].record(A)
                 B.wait_event(sorted_ev[k])
                 check(lib.gsr_bin_sort(n, C.byref(cam), C.byref(opts), mp, ws.data_ptr(), ws.numel(), B.cuda_stream))
-                check(lib.gsr_blend(n, C.byref(cam), C.byref(opts), mp, ws.data_ptr(), ws.numel(), outs[k].data_ptr(), None, B.cuda_stream))
+                check(lib.gsr_blend(None, n, C.byref(cam), C.byref(opts), mp, ws.data_ptr(), ws.numel(), outs[k].data_ptr(), None, B.cuda_stream))
                 blended_ev[k].record(B)
             return
         for f in range(K):
@@ -71,7 +71,7 @@ for NW in [int(x) for x in (sys.argv[1:] or ["2", "3", "4"])]:
             check(lib.gsr_bin_sort(n, C.byref(cam), C.byref(opts), mp, ws.data_ptr(), ws.numel(), A.cuda_stream))
             sorted_ev[k].record(A)
             B.wait_event(sorted_ev[k])
-            check(lib.gsr_blend(n, C.byref(cam), C.byref(opts), mp, ws.data_ptr(), ws.numel(), outs[k].data_ptr(), None, B.cuda_stream))
+            check(lib.gsr_blend(None, n, C.byref(cam), C.byref(opts), mp, ws.data_ptr(), ws.numel(), outs[k].data_ptr(), None, B.cuda_stream))
             blended_ev[k].record(B)
 
     run(2 * NW + 2); torch.cuda.synchronize()

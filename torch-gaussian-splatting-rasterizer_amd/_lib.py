@@ -23,6 +23,7 @@ GSR_ERR_PAIR_OVERFLOW = -3
 GSR_ERR_HIP = -4
 GSR_ERR_SORT_PASSES = -5
 GSR_MAX_PAIRS = 0xFFFFE000  # include/gsr.h
+GSR_MAX_BATCH_VIEWS = 8
 
 
 class GsrError(RuntimeError):
@@ -89,6 +90,7 @@ class GsrOptions(C.Structure):
         ("no_order_hint", C.c_int32),
         ("colour_stage", C.c_int32),
         ("sh_dense_min", C.c_int32),
+        ("batch_views", C.c_int32),
     ]
 
 
@@ -139,7 +141,7 @@ def _load() -> C.CDLL:
     L.gsr_preprocess.argtypes = [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrOptions), vp, sz,
                                  C.POINTER(GsrDebugOut), vp]
     L.gsr_bin_sort.argtypes = [i64, C.POINTER(GsrCamera), C.POINTER(GsrOptions), i64, vp, sz, vp]
-    L.gsr_blend.argtypes = [i64, C.POINTER(GsrCamera), C.POINTER(GsrOptions), i64, vp, sz, vp, vp, vp]
+    L.gsr_blend.argtypes = [C.POINTER(GsrScene), i64, C.POINTER(GsrCamera), C.POINTER(GsrOptions), i64, vp, sz, vp, vp, vp]
     L.gsr_render_forward.argtypes = [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrOptions), i64, vp, sz, vp, vp, vp]
     L.gsr_render_batch.argtypes = [C.POINTER(GsrScene), C.POINTER(GsrCamera), i32, C.POINTER(GsrOptions), i64, vp, sz, vp, i64, vp]
     L.gsr_render_batch_slots.argtypes = [C.POINTER(GsrScene), C.POINTER(GsrCamera), i32, C.POINTER(GsrOptions), i64, C.POINTER(vp), sz,

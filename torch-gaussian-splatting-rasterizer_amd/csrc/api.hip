@@ -96,6 +96,7 @@ static int check_frame(int64_t n, const GsrCamera *cam, const GsrOptions *opts, 
     if (opts->no_order_hint != 0 && opts->no_order_hint != 1) { set_error("bad no_order_hint %d", opts->no_order_hint); return GSR_ERR_BAD_ARG; }
     if (opts->colour_stage != 0 && opts->colour_stage != 1) { set_error("bad colour_stage %d", opts->colour_stage); return GSR_ERR_BAD_ARG; }
     if (opts->sh_dense_min < 0 || opts->sh_dense_min > 65) { set_error("bad sh_dense_min %d", opts->sh_dense_min); return GSR_ERR_BAD_ARG; }
+    if (opts->batch_views < 0 || opts->batch_views > MAX_VIEWS) { set_error("bad batch_views %d (0 .. %d)", opts->batch_views, MAX_VIEWS); return GSR_ERR_BAD_ARG; }
     if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) { set_error("workspace must be 256-byte aligned"); return GSR_ERR_BAD_ARG; }
     const size_t need = carve_workspace(workspace, n, cam->width, cam->height, max_pairs, ws);
     if (workspace_bytes < need) {
@@ -219,17 +220,16 @@ static int check_scene(const GsrScene *sc)
     return GSR_OK;
 }
 
-static int preprocess_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
-                           size_t workspace_bytes, const GsrDebugOut *debug, void *stream, bool keep_batch_words);
+// how much of a view's control block its frame clears: a fresh workspace may hold anything, so the default clears the whole block
+// (a 0xFF-filled one renders correctly); keep_flags / the later views of a batch keep the sticky record at its tail
+static int reset_words_of(const GsrOptions *opts, bool keep_batch_words)
+{
+    static_assert(sizeof(FrameCtrl) % 4 == 0 && offsetof(FrameCtrl, batch_overflow) % 4 == 0, "FrameCtrl is cleared by words");
+    return (int)((keep_batch_words || opts->keep_flags ? offsetof(FrameCtrl, batch_overflow) : sizeof(FrameCtrl)) / 4);
+}
 
 int gsr_preprocess(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
                    size_t workspace_bytes, const GsrDebugOut *debug, void *stream)
-{
-    return preprocess_impl(scene, cam, opts, workspace, workspace_bytes, debug, stream, false);
-}
-
-static int preprocess_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, void *workspace,
-                           size_t workspace_bytes, const GsrDebugOut *debug, void *stream, bool keep_batch_words)
 {
     int rc = check_scene(scene);
     if (rc) return rc;
@@ -238,12 +238,16 @@ static int preprocess_impl(const GsrScene *scene, const GsrCamera *cam, const Gs
     // so size-check against the smallest one.
     rc = check_frame(scene->n, cam, opts, 0, workspace, workspace_bytes, &ws);
     if (rc) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    static_assert(sizeof(FrameCtrl) % 4 == 0 && offsetof(FrameCtrl, batch_overflow) % 4 == 0, "FrameCtrl is cleared by words");
-    // a fresh workspace may hold anything: the default clears the whole block (so does a 0xFF-filled one render correctly);
-    // keep_flags / the later views of a batch keep the sticky record at its tail
-    const int reset_words = (int)((keep_batch_words || opts->keep_flags ? offsetof(FrameCtrl, batch_overflow) : sizeof(FrameCtrl)) / 4);
-    return launch_preprocess(*scene, *cam, *opts, ws, debug, reset_words, s);
+    return launch_preprocess(*scene, cam, *opts, ws, debug, reset_words_of(opts, false), static_cast<hipStream_t>(stream));
+}
+
+// depth order: pass 0 drops culled gaussians and leaves V in ctrl; 3 passes on ordinary scenes (sort.hip); then pairs in depth
+// order, stably sorted by tile -> per-tile lists and their ranges; E in ctrl
+static int bin_sort_impl(const GsrOptions *opts, const Workspace &ws, hipStream_t s)
+{
+    const int rc = launch_depth_sort(ws, rect_fits_8bit(ws), shard_compact(*opts), opts->depth_sort_passes, s);
+    if (rc) return rc;
+    return launch_binning(*opts, ws, s);
 }
 
 int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs, void *workspace,
@@ -252,64 +256,105 @@ int gsr_bin_sort(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_
     Workspace ws;
     int rc = check_frame(n, cam, opts, max_pairs, workspace, workspace_bytes, &ws);
     if (rc) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    // depth order: pass 0 drops culled gaussians and leaves V in ctrl; 3 passes on ordinary scenes (sort.hip)
-    rc = launch_depth_sort(ws, rect_fits_8bit(ws), shard_compact(*opts), opts->depth_sort_passes, s);
-    if (rc) return rc;
-    // pairs in depth order, stably sorted by tile -> per-tile lists and their ranges; E in ctrl
-    return launch_binning(*opts, ws, s);
+    return bin_sort_impl(opts, ws, static_cast<hipStream_t>(stream));
 }
 
-int gsr_blend(int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs, void *workspace,
+int gsr_blend(const GsrScene *scene, int64_t n, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs, void *workspace,
               size_t workspace_bytes, void *out_image, float *out_final_T, void *stream)
 {
     if (!out_image) { set_error("null output image"); return GSR_ERR_BAD_ARG; }
+    if (scene) {
+        const int rc = check_scene(scene);
+        if (rc) return rc;
+        if (scene->n != n) { set_error("scene->n = %lld but n = %lld", (long long)scene->n, (long long)n); return GSR_ERR_BAD_ARG; }
+    }
     Workspace ws;
     int rc = check_frame(n, cam, opts, max_pairs, workspace, workspace_bytes, &ws);
     if (rc) return rc;
-    return launch_blend(*cam, *opts, ws, tile_lists(ws, *opts), out_image, out_final_T, static_cast<hipStream_t>(stream));
+    return launch_blend(*cam, *opts, ws, tile_lists(ws, *opts), out_image, 0, out_final_T, scene, static_cast<hipStream_t>(stream));
 }
 
-static int render_forward_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,
-                               void *workspace, size_t workspace_bytes, void *out_image, float *out_final_T, void *stream,
-                               bool keep_batch_words);
+// Stages 1-3 for `views` cameras through ONE launch sequence: view v works in slice v of the workspace (slices of
+// gsr_workspace_bytes() bytes) and renders into out_images + v * out_view_stride bytes.
+static int render_views(const GsrScene *scene, const GsrCamera *cams, int views, const GsrOptions *opts, int64_t max_pairs,
+                        void *workspace, size_t workspace_bytes, void *out_images, size_t out_view_stride, float *out_final_T,
+                        void *stream, bool keep_batch_words)
+{
+    int rc = check_scene(scene);
+    if (rc) return rc;
+    if (!out_images) { set_error("null output image"); return GSR_ERR_BAD_ARG; }
+    if (!cams || views < 1 || views > MAX_VIEWS || (views > 1 && out_final_T)) { set_error("bad view count %d", views); return GSR_ERR_BAD_ARG; }
+    Workspace ws;
+    rc = check_frame(scene->n, &cams[0], opts, max_pairs, workspace, workspace_bytes, &ws);
+    if (rc) return rc;
+    if (views > 1) {
+        if (workspace_bytes / ws.bytes < (size_t)views) {
+            set_error("workspace too small for %d views per launch: %zu bytes given, %zu needed", views, workspace_bytes, ws.bytes * (size_t)views);
+            return GSR_ERR_WORKSPACE;
+        }
+        ws.views = views;
+        ws.view_stride = ws.bytes;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = launch_preprocess(*scene, cams, *opts, ws, nullptr, reset_words_of(opts, keep_batch_words), s);
+    if (rc) return rc;
+    rc = bin_sort_impl(opts, ws, s);
+    if (rc) return rc;
+    // (the blend finds the scene through what the preprocess above left in each view's control block: same call, same arrays)
+    return launch_blend(cams[0], *opts, ws, tile_lists(ws, *opts), out_images, out_view_stride, out_final_T, nullptr, s);
+}
 
 int gsr_render_forward(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,
                        void *workspace, size_t workspace_bytes, void *out_image, float *out_final_T, void *stream)
 {
-    return render_forward_impl(scene, cam, opts, max_pairs, workspace, workspace_bytes, out_image, out_final_T, stream, false);
+    if (!cam || !opts) { set_error("null camera/options"); return GSR_ERR_BAD_ARG; }
+    return render_views(scene, cam, 1, opts, max_pairs, workspace, workspace_bytes, out_image, 0, out_final_T, stream, false);
 }
 
-static int render_forward_impl(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, int64_t max_pairs,
-                               void *workspace, size_t workspace_bytes, void *out_image, float *out_final_T, void *stream,
-                               bool keep_batch_words)
+// How many views go through one launch sequence: as many slices as the workspace holds, at most MAX_VIEWS, GsrOptions.batch_views
+// (when set) and the views there are.  0: the workspace does not hold one view.
+static int views_per_launch(const GsrScene *scene, const GsrCamera *cam0, const GsrOptions *opts, int64_t max_pairs, size_t workspace_bytes, int32_t n_cams)
 {
-    int rc = check_scene(scene);
-    if (rc) return rc;
-    if (!out_image) { set_error("null output image"); return GSR_ERR_BAD_ARG; }
     Workspace ws;
-    rc = check_frame(scene->n, cam, opts, max_pairs, workspace, workspace_bytes, &ws);
-    if (rc) return rc;
-    rc = preprocess_impl(scene, cam, opts, workspace, workspace_bytes, nullptr, stream, keep_batch_words);
-    if (rc) return rc;
-    rc = gsr_bin_sort(scene->n, cam, opts, max_pairs, workspace, workspace_bytes, stream);
-    if (rc) return rc;
-    return gsr_blend(scene->n, cam, opts, max_pairs, workspace, workspace_bytes, out_image, out_final_T, stream);
+    const size_t per = carve_workspace(nullptr, scene->n, cam0->width, cam0->height, max_pairs, &ws);
+    size_t k = workspace_bytes / per;
+    k = std::min<size_t>(k, (size_t)MAX_VIEWS);
+    if (opts->batch_views > 0) k = std::min<size_t>(k, (size_t)opts->batch_views);
+    return (int)std::min<size_t>(k, (size_t)std::max<int32_t>(n_cams, 1));
+}
+
+static int check_batch(const GsrScene *scene, const GsrCamera *cams, int32_t n_cams, const GsrOptions *opts, int64_t max_pairs, const void *out_images,
+                       int64_t frame_stride)
+{
+    if (!scene || !cams || n_cams < 0 || !out_images || !opts) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
+    if (scene->n < 0 || scene->n > 0x7FFFFFFF || max_pairs < 0) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
+    for (int32_t i = 0; i < n_cams; ++i) {
+        if (cams[i].width <= 0 || cams[i].height <= 0) { set_error("bad frame size %dx%d", cams[i].width, cams[i].height); return GSR_ERR_BAD_ARG; }
+        if (cams[i].width != cams[0].width || cams[i].height != cams[0].height) { set_error("views of a batch must share one frame size"); return GSR_ERR_BAD_ARG; }
+    }
+    // what one view writes: the frame, or (output_layout = 2) the strip of its shard's tile rows
+    int64_t rows_px = cams[0].height;
+    if (n_cams > 0 && opts->output_layout == 2) {
+        const int step = std::max(opts->tile_row_step, 1), tiles_y = (cams[0].height + GSR_TILE - 1) / GSR_TILE;
+        rows_px = opts->tile_row_begin < tiles_y ? (int64_t)((tiles_y - opts->tile_row_begin + step - 1) / step) * GSR_TILE : 0;
+    }
+    if (n_cams > 0 && frame_stride < (int64_t)cams[0].width * rows_px * 3) { set_error("frame_stride smaller than a frame"); return GSR_ERR_BAD_ARG; }
+    return GSR_OK;
 }
 
 int gsr_render_batch(const GsrScene *scene, const GsrCamera *cams, int32_t n_cams, const GsrOptions *opts, int64_t max_pairs,
                      void *workspace, size_t workspace_bytes, void *out_images, int64_t frame_stride, void *stream)
 {
-    if (!cams || n_cams < 0 || !out_images || !opts) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
-    for (int32_t i = 0; i < n_cams; ++i) {
-        if (cams[i].width != cams[0].width || cams[i].height != cams[0].height) { set_error("views of a batch must share one frame size"); return GSR_ERR_BAD_ARG; }
-        if (frame_stride < (int64_t)cams[i].width * cams[i].height * 3) { set_error("frame_stride smaller than a frame"); return GSR_ERR_BAD_ARG; }
-    }
-    for (int32_t i = 0; i < n_cams; ++i) {
-        // view 0 clears the whole control block, later views keep the batch-sticky overflow words
-        int rc = render_forward_impl(scene, &cams[i], opts, max_pairs, workspace, workspace_bytes,
-                                     static_cast<char *>(out_images) + (size_t)i * frame_stride * (opts->output_dtype == 1 ? 2 : 4), nullptr, stream,
-                                     i > 0);
+    int rc = check_batch(scene, cams, n_cams, opts, max_pairs, out_images, frame_stride);
+    if (rc || n_cams == 0) return rc;
+    const int K = views_per_launch(scene, &cams[0], opts, max_pairs, workspace_bytes, n_cams);
+    const size_t fbytes = (size_t)frame_stride * (opts->output_dtype == 1 ? 2 : 4);
+    for (int32_t i = 0; i < n_cams; i += std::max(K, 1)) {
+        // K = 0: the workspace does not hold one view — render_views reports it.  A slice's first view clears its whole control
+        // block, its later views (i >= K) keep the batch-sticky overflow words
+        const int k = std::max(1, std::min<int32_t>(K, n_cams - i));
+        rc = render_views(scene, &cams[i], k, opts, max_pairs, workspace, workspace_bytes, static_cast<char *>(out_images) + (size_t)i * fbytes,
+                          fbytes, nullptr, stream, i > 0);
         if (rc) return rc;
     }
     return GSR_OK;
@@ -319,22 +364,24 @@ int gsr_render_batch_slots(const GsrScene *scene, const GsrCamera *cams, int32_t
                            void *const *workspaces, size_t workspace_bytes, void *const *streams, int32_t n_slots, void *out_images,
                            int64_t frame_stride)
 {
-    if (!cams || n_cams < 0 || !out_images || !opts || !workspaces || !streams || n_slots < 1) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
+    if (!workspaces || !streams || n_slots < 1) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
+    int rc = check_batch(scene, cams, n_cams, opts, max_pairs, out_images, frame_stride);
+    if (rc) return rc;
     for (int32_t k = 0; k < n_slots; ++k) {
         if (!workspaces[k]) { set_error("null workspace in slot %d", (int)k); return GSR_ERR_BAD_ARG; }
         for (int32_t j = 0; j < k; ++j)
             if (workspaces[j] == workspaces[k]) { set_error("slots %d and %d share a workspace", (int)j, (int)k); return GSR_ERR_BAD_ARG; }
     }
-    for (int32_t i = 0; i < n_cams; ++i) {
-        if (cams[i].width != cams[0].width || cams[i].height != cams[0].height) { set_error("views of a batch must share one frame size"); return GSR_ERR_BAD_ARG; }
-        if (frame_stride < (int64_t)cams[i].width * cams[i].height * 3) { set_error("frame_stride smaller than a frame"); return GSR_ERR_BAD_ARG; }
-    }
-    for (int32_t i = 0; i < n_cams; ++i) {
-        const int32_t k = i % n_slots;
-        // a slot's first view clears its whole control block, its later views keep the batch-sticky overflow words
-        int rc = render_forward_impl(scene, &cams[i], opts, max_pairs, workspaces[k], workspace_bytes,
-                                     static_cast<char *>(out_images) + (size_t)i * frame_stride * (opts->output_dtype == 1 ? 2 : 4), nullptr,
-                                     streams[k], i >= n_slots);
+    if (n_cams == 0) return GSR_OK;
+    const int K = views_per_launch(scene, &cams[0], opts, max_pairs, workspace_bytes, n_cams);
+    const size_t fbytes = (size_t)frame_stride * (opts->output_dtype == 1 ? 2 : 4);
+    int32_t g = 0;
+    for (int32_t i = 0; i < n_cams; i += std::max(K, 1), ++g) {
+        const int32_t slot = g % n_slots;
+        const int k = std::max(1, std::min<int32_t>(K, n_cams - i));
+        // a slot's first group clears its slices' control blocks, its later groups keep the batch-sticky overflow words
+        rc = render_views(scene, &cams[i], k, opts, max_pairs, workspaces[slot], workspace_bytes, static_cast<char *>(out_images) + (size_t)i * fbytes,
+                          fbytes, nullptr, streams[slot], g >= n_slots);
         if (rc) return rc;
     }
     return GSR_OK;

@@ -110,8 +110,11 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t
                                                                   const FrameCtrl *ctrl, const ushort4 *__restrict__ rect, Shard sh,
                                                                   uint32_t *__restrict__ blk_sum, uint2 *__restrict__ ranges,
                                                                   int n_tiles, uint32_t draw_limit, uint2 *__restrict__ cranges, int n_ctiles,
-                                                                  FrameCtrl *ctrl_w, uint32_t ent_off, int nblk_n)
+                                                                  FrameCtrl *ctrl_w, uint32_t ent_off, int nblk_n, size_t vstride)
 {
+    id_a = view_slice(id_a, vstride); id_b = view_slice(id_b, vstride); r8_a = view_slice(r8_a, vstride); r8_b = view_slice(r8_b, vstride);
+    ctrl = view_slice(ctrl, vstride); rect = view_slice(rect, vstride); blk_sum = view_slice(blk_sum, vstride); ranges = view_slice(ranges, vstride);
+    cranges = view_slice(cranges, vstride); ctrl_w = view_slice(ctrl_w, vstride);
     const uint32_t n = ctrl->n_visible;
     const uint32_t t = blockIdx.x * EMIT_THREADS + threadIdx.x;
     // threads in the grid (not gridDim.x: that would pull in the hidden kernarg block)
@@ -152,11 +155,12 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t
 // consecutive sums per thread (four 16-B loads), so a 6 M-gaussian frame is one trip: serial scan in registers,
 // wave scan, 16 wave totals through LDS.  64-bit partials so that a D beyond 2^32 is still caught as overflow.
 __global__ __launch_bounds__(1024) void pair_scan_kernel(uint32_t *__restrict__ blk_sum, int nblk_bound, FrameCtrl *ctrl,
-                                                         uint32_t max_pairs)
+                                                         uint32_t max_pairs, size_t vstride)
 {
     constexpr int PER = 16;
     __shared__ unsigned long long wsum[16];
     __shared__ unsigned long long s_carry;
+    blk_sum = view_slice(blk_sum, vstride); ctrl = view_slice(ctrl, vstride);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n = ctrl->n_visible;
     const int nblk = min(nblk_bound, (int)((n + EMIT_THREADS - 1) / EMIT_THREADS));
@@ -230,8 +234,12 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
                                                                  int bits_x, int tiles_y, const GaussRec *__restrict__ rec,
                                                                  const uint32_t *blk_off, uint32_t max_pairs,
                                                                  uint32_t *__restrict__ pkey, uint32_t *__restrict__ pval,
-                                                                 uint32_t draw_limit, Shard tsh, uint32_t *blk_entries /* = blk_off: no __restrict__ on either */)
+                                                                 uint32_t draw_limit, Shard tsh, uint32_t *blk_entries /* = blk_off: no __restrict__ on either */,
+                                                                 size_t vstride)
 {
+    id_a = view_slice(id_a, vstride); id_b = view_slice(id_b, vstride); r8_a = view_slice(r8_a, vstride); r8_b = view_slice(r8_b, vstride);
+    ctrl = view_slice(ctrl, vstride); rect = view_slice(rect, vstride); rec = view_slice(rec, vstride); blk_off = view_slice(blk_off, vstride);
+    pkey = view_slice(pkey, vstride); pval = view_slice(pval, vstride); blk_entries = view_slice(blk_entries, vstride);
     __shared__ uint32_t scratch[8];
     __shared__ uint32_t s_off[EMIT_THREADS];   // exclusive pair offset of each gaussian inside the workgroup
     __shared__ uint32_t s_id[EMIT_THREADS];
@@ -323,8 +331,9 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
 
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t *__restrict__ pkey, const uint32_t *n_dev,
                                                           uint2 *__restrict__ ranges, int bits_x, int tiles_x, int n_tiles,
-                                                          uint32_t stride)
+                                                          uint32_t stride, size_t vstride)
 {
+    pkey = view_slice(pkey, vstride); n_dev = view_slice(n_dev, vstride); ranges = view_slice(ranges, vstride);
     // four keys per thread from one 16-B load; only the two keys flanking the group are read a second time.
     // stride = threads in the grid, passed in: gridDim / blockDim would pull in the 256-B hidden kernarg block
     const uint32_t n = *n_dev;
@@ -392,10 +401,14 @@ int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s)
 {
     const int n_tiles = ws.tiles_x * ws.tiles_y;
     if (ws.n <= 0) {  // no count kernel to clear the ranges (per tile, and per cell for a blend that reads the cell lists)
-        GSR_HIP(hipMemsetAsync(ws.ranges, 0, sizeof(uint2) * (size_t)n_tiles, s));
-        GSR_HIP(hipMemsetAsync(ws.cranges, 0, sizeof(uint2) * (size_t)ws.ctiles_x * ws.ctiles_y, s));
+        for (int v = 0; v < ws.views; ++v) {
+            GSR_HIP(hipMemsetAsync(reinterpret_cast<char *>(ws.ranges) + v * ws.view_stride, 0, sizeof(uint2) * (size_t)n_tiles, s));
+            GSR_HIP(hipMemsetAsync(reinterpret_cast<char *>(ws.cranges) + v * ws.view_stride, 0, sizeof(uint2) * (size_t)ws.ctiles_x * ws.ctiles_y, s));
+        }
         return GSR_OK;
     }
+    const unsigned nv = (unsigned)ws.views;  // gridDim.y: one workspace slice per view
+    const size_t vs = ws.view_stride;
     const bool packed_rect = rect_fits_8bit(ws);
     const Shard sh = {opts.tile_row_begin, opts.tile_row_step < 1 ? 1 : opts.tile_row_step};
     // cells of a shard: with an even row step the rank's tile rows begin + k step fall into the cell rows (begin >> 1) + k (step >> 1),
@@ -409,14 +422,14 @@ int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s)
     const int nblk_n = (int)((ws.n + EMIT_THREADS - 1) / EMIT_THREADS);                       // emit blocks (the bound: n >= V)
     const int nblk_count = (nblk_n + COUNT_BLOCKS_PER_WG - 1) / COUNT_BLOCKS_PER_WG;          // the count kernel: one wave per emit block
                                                                                               // (it also zeroes ranges[] / cranges[], grid-stride)
-#define GSR_COUNT(P, C) hipLaunchKernelGGL((pair_count_kernel<P, C>), dim3(nblk_count), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
+#define GSR_COUNT(P, C) hipLaunchKernelGGL((pair_count_kernel<P, C>), dim3(nblk_count, nv), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
                                            ws.ctrl, ws.rect, C ? csh : sh, ws.blk_sum, ws.ranges, n_tiles, limit, ws.cranges, n_ctiles, ws.ctrl, \
-                                           C ? (uint32_t)(reinterpret_cast<const char *>(ws.blk_sum) - reinterpret_cast<const char *>(ws.ctrl)) : 0u, nblk_n)
-#define GSR_EMIT(P, C) hipLaunchKernelGGL((pair_emit_kernel<P, C>), dim3(nblk_n), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
+                                           C ? (uint32_t)(reinterpret_cast<const char *>(ws.blk_sum) - reinterpret_cast<const char *>(ws.ctrl)) : 0u, nblk_n, vs)
+#define GSR_EMIT(P, C) hipLaunchKernelGGL((pair_emit_kernel<P, C>), dim3(nblk_n, nv), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
                                           ws.ctrl, ws.rect, C ? csh : sh, tk.bits_x, tk.grid_y, ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0], limit, \
-                                          sh, ws.blk_sum)
+                                          sh, ws.blk_sum, vs)
     if (tk.coarse) GSR_COUNT(true, true); else if (packed_rect) GSR_COUNT(true, false); else GSR_COUNT(false, false);
-    hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, ws.blk_sum, nblk_n, ws.ctrl, cap);
+    hipLaunchKernelGGL(pair_scan_kernel, dim3(1, nv), dim3(1024), 0, s, ws.blk_sum, nblk_n, ws.ctrl, cap, vs);
     if (tk.coarse) GSR_EMIT(true, true); else if (packed_rect) GSR_EMIT(true, false); else GSR_EMIT(false, false);
 #undef GSR_COUNT
 #undef GSR_EMIT
@@ -428,8 +441,8 @@ int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s)
     const int rc = launch_pair_sort(ws, 0, &ws.ctrl->n_slots, 0, tk.bits_x + tk.bits_y, tk.drop_from, n_sorted, &pbuf, s);
     if (rc) return rc;
     const int grid = (int)std::min<int64_t>((ws.max_pairs + 1023) / 1024, 8192);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(grid), dim3(256), 0, s, ws.pkey[pbuf], n_sorted, tk.coarse ? ws.cranges : ws.ranges, tk.bits_x,
-                       tk.grid_x, tk.grid_x * tk.grid_y, (uint32_t)grid * 256u);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(grid, nv), dim3(256), 0, s, ws.pkey[pbuf], n_sorted, tk.coarse ? ws.cranges : ws.ranges, tk.bits_x,
+                       tk.grid_x, tk.grid_x * tk.grid_y, (uint32_t)grid * 256u, vs);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

@@ -55,14 +55,22 @@ __device__ __forceinline__ T ldg(const T *p, size_t i)
 // entries.  Races are benign by construction: every writer stores the same three values, and a reader accepts the record's
 // colour only when all three channels are non-negative — whatever mix of old and new words it sees (another XCD's L2 may still
 // hold the line from before), it either uses the final values or evaluates them itself.
+// The record's q2 is read and written through relaxed agent-scope atomics, word by word: the race between the tiles that stage one gaussian is
+// deliberate (see above), and this is how the compiler is told — it may neither cache the words nor tear the stores further.
+__device__ __forceinline__ float q2_load(const float *w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void q2_store(float *w, float v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ float4 staged_q2(const BlendArgs &a, uint32_t id, uint32_t &evals)
 {
-    GaussRec *r = a.rec + id;
-    float4 q2 = r->q2;
+    float *w = reinterpret_cast<float *>(&a.rec[id].q2);
+    float4 q2 = make_float4(q2_load(w), q2_load(w + 1), q2_load(w + 2), q2_load(w + 3));
     if (!(q2.y >= 0.0f && q2.z >= 0.0f && q2.w >= 0.0f)) {
         const FrameCtrl *c = a.ctrl;
-        const float cc[3] = {c->col_cc[0], c->col_cc[1], c->col_cc[2]};
-        const float p[3] = {ldg(c->col_means, 3 * (size_t)id), ldg(c->col_means, 3 * (size_t)id + 1), ldg(c->col_means, 3 * (size_t)id + 2)};
+        const bool own = a.col_means != nullptr;  // uniform: gsr_blend was handed the scene
+        const float *means = own ? a.col_means : c->col_means;
+        const void *sh = own ? a.col_sh : c->col_sh;
+        const float cc[3] = {own ? a.col_cc[0] : c->col_cc[0], own ? a.col_cc[1] : c->col_cc[1], own ? a.col_cc[2] : c->col_cc[2]};
+        const float p[3] = {ldg(means, 3 * (size_t)id), ldg(means, 3 * (size_t)id + 1), ldg(means, 3 * (size_t)id + 2)};
         float rgb[3];
         // The evaluation consumes the row in memory order (sh_eval_with) and each element is loaded where it is consumed (the compiler
         // merges them into 16-B loads, one in flight at a time): this runs inside a 64-VGPR kernel whose accumulators stay live, and
@@ -72,9 +80,9 @@ __device__ __forceinline__ float4 staged_q2(const BlendArgs &a, uint32_t id, uin
         // 3.00 M evaluations — ~31 ns per 1000 evaluations in every variant, the rate at which the preprocess read the rows it
         // needed (650 MB in 0.11 ms): the saving is the rows never read.  The degree is a constant per branch (the reference
         // always evaluates 3, rasterize.py:368).
-        const int degree = c->col_degree;
-        if (c->col_sh16) {
-            const unsigned *row = reinterpret_cast<const unsigned *>(static_cast<const char *>(c->col_sh) + 96 * (size_t)id);
+        const int degree = own ? a.col_degree : c->col_degree;
+        if (own ? a.col_sh16 : c->col_sh16) {
+            const unsigned *row = reinterpret_cast<const unsigned *>(static_cast<const char *>(sh) + 96 * (size_t)id);
             auto get = [row](int e) {
                 const unsigned w = ldg(row, (size_t)(e >> 1));
                 return __half2float(__ushort_as_half((unsigned short)((e & 1) ? w >> 16 : w & 0xFFFFu)));
@@ -82,13 +90,13 @@ __device__ __forceinline__ float4 staged_q2(const BlendArgs &a, uint32_t id, uin
             if (degree == 3) sh_eval_with(p, get, cc, 3, rgb);
             else sh_eval_with(p, get, cc, degree, rgb);
         } else {
-            const float *row = static_cast<const float *>(c->col_sh) + 48 * (size_t)id;
+            const float *row = static_cast<const float *>(sh) + 48 * (size_t)id;
             auto get = [row](int e) { return ldg(row, e); };
             if (degree == 3) sh_eval_with(p, get, cc, 3, rgb);
             else sh_eval_with(p, get, cc, degree, rgb);
         }
         q2.y = rgb[0]; q2.z = rgb[1]; q2.w = rgb[2];
-        r->q2 = q2;
+        q2_store(w + 1, q2.y); q2_store(w + 2, q2.z); q2_store(w + 3, q2.w);  // (w[0], log2 opacity, is the preprocess's and final)
         ++evals;
     }
     return q2;
@@ -892,9 +900,11 @@ __device__ __forceinline__ void stat_colour_evals(uint32_t mine, uint32_t *s_col
 __global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict__ ranges, FrameCtrl *ctrl, int tiles_x,
                                                          int row_begin, int row_step, int rows, int slots_per_group,
                                                          int *__restrict__ order, uint32_t stats_off, const uint2 *__restrict__ cranges,
-                                                         int ctiles_x, const uint32_t *__restrict__ tile_work)
+                                                         int ctiles_x, const uint32_t *__restrict__ tile_work, size_t vstride)
 {
     constexpr int NB = 256;
+    ranges = view_slice(ranges, vstride); ctrl = view_slice(ctrl, vstride); order = view_slice(order, vstride);
+    cranges = view_slice(cranges, vstride); tile_work = view_slice(tile_work, vstride);
     __shared__ uint32_t bucket_cnt[NB];
     __shared__ uint32_t bucket_start[NB];
     __shared__ uint32_t scratch[8];
@@ -947,8 +957,9 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict
 // The plain-C statement of the blend (GsrOptions.blend_impl = 1): one 256-thread workgroup per tile, wave = 8x8 quadrant, lane =
 // pixel.  The reference for the hand-scheduled kernel below, and what round 1 shipped.
 template <bool BF16ACC>  // GsrOptions.accum_dtype = 1: T and the colour sums live in bfloat16 (rounded to nearest even after every gaussian)
-__global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
+__global__ __launch_bounds__(256) void blend_kernel(BlendArgs args)
 {
+    const BlendArgs a = blend_args_of_view(args);
     auto acc_round = [](float &T, float &Cr, float &Cg, float &Cb) {
         if (BF16ACC) { T = bf16_round(T); Cr = bf16_round(Cr); Cg = bf16_round(Cg); Cb = bf16_round(Cb); }
     };
@@ -1062,8 +1073,9 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a)
 // 0.52 vs 0.65 ms), so launch_blend picks by tile count.  Same lists, same per-quadrant classification and saturation tests,
 // same arithmetic as blend_kernel.
 template <int QPW, bool PIPE>  // PIPE (QPW = 1 only): the pipelined walk, 96 VGPRs, for grids that 5 waves per SIMD hold
-__global__ __launch_bounds__(256 / QPW, PIPE ? 5 : 8) void blend_walk_kernel(BlendArgs a)
+__global__ __launch_bounds__(256 / QPW, PIPE ? 5 : 8) void blend_walk_kernel(BlendArgs args)
 {
+    const BlendArgs a = blend_args_of_view(args);
     static_assert(!PIPE || QPW == 1, "the pipelined walk evaluates one quadrant per wave");
     constexpr int THREADS = 256 / QPW, BATCH = THREADS, WAVES = THREADS / 64;
     __shared__ float4 srec[3][BATCH];  // planes BATCH * 16 B apart
@@ -1188,9 +1200,18 @@ constexpr int BLEND_HALF_MIN_TILES = GSR_BLEND_HALF_MIN_TILES;  // (the macro: t
 constexpr int BLEND_PIPE_MAX_TILES = 1280;
 
 int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, const uint32_t *lists, void *out_image,
-                 float *out_T, hipStream_t s)
+                 size_t out_view_stride, float *out_T, const GsrScene *scene, hipStream_t s)
 {
+    if (ws.views > 1 && (out_T || scene)) { set_error("final T / an explicit scene: single views only"); return GSR_ERR_BAD_ARG; }
     BlendArgs a;
+    a.col_means = scene ? scene->means : nullptr;
+    a.col_sh = scene ? scene->sh : nullptr;
+    a.col_cc[0] = cam.cam_center[0]; a.col_cc[1] = cam.cam_center[1]; a.col_cc[2] = cam.cam_center[2];
+    a.col_degree = scene ? scene->sh_degree : 0;
+    a.col_sh16 = scene ? scene->sh_dtype : 0;
+    a.view_stride = ws.view_stride;
+    a.out_view_stride = out_view_stride;
+    const unsigned nv = (unsigned)ws.views;  // gridDim.y: one workspace slice and one frame per view
     a.ranges = ws.ranges;
     a.cranges = ws.cranges;
     a.ctiles_x = ws.ctiles_x;
@@ -1219,15 +1240,18 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     const int rows_per_xcd = (a.rows + 7) / 8;
     const int slots_per_group = rows_per_xcd * a.tiles_x;
     a.order = ws.tile_order;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(256), 0, s, ws.ranges, ws.ctrl, a.tiles_x, a.row_begin, a.row_step, a.rows,
+    hipLaunchKernelGGL(tile_order_kernel, dim3(8, nv), dim3(256), 0, s, ws.ranges, ws.ctrl, a.tiles_x, a.row_begin, a.row_step, a.rows,
                        slots_per_group, ws.tile_order,
                        (uint32_t)(reinterpret_cast<const char *>(ws.blend_stats) - reinterpret_cast<const char *>(ws.ctrl)),
-                       a.cell_lists ? ws.cranges : nullptr, ws.ctiles_x, opts.no_order_hint ? nullptr : ws.tile_work);
-    if (opts.accum_dtype == 1) hipLaunchKernelGGL(blend_kernel<true>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
-    else if (opts.blend_impl == 1) hipLaunchKernelGGL(blend_kernel<false>, dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
-    else if (a.rows * a.tiles_x >= BLEND_HALF_MIN_TILES) hipLaunchKernelGGL((blend_walk_kernel<2, false>), dim3(8u * (unsigned)slots_per_group), dim3(128), 0, s, a);
-    else if (a.rows * a.tiles_x <= pipe_max_tiles) hipLaunchKernelGGL((blend_walk_kernel<1, true>), dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((blend_walk_kernel<1, false>), dim3(8u * (unsigned)slots_per_group), dim3(256), 0, s, a);
+                       a.cell_lists ? ws.cranges : nullptr, ws.ctiles_x, opts.no_order_hint ? nullptr : ws.tile_work, ws.view_stride);
+    // which walk: by the tiles of the whole launch (all views: what fills the machine)
+    const int launch_tiles = a.rows * a.tiles_x * ws.views;
+    const dim3 grid(8u * (unsigned)slots_per_group, nv);
+    if (opts.accum_dtype == 1) hipLaunchKernelGGL(blend_kernel<true>, grid, dim3(256), 0, s, a);
+    else if (opts.blend_impl == 1) hipLaunchKernelGGL(blend_kernel<false>, grid, dim3(256), 0, s, a);
+    else if (launch_tiles >= BLEND_HALF_MIN_TILES) hipLaunchKernelGGL((blend_walk_kernel<2, false>), grid, dim3(128), 0, s, a);
+    else if (launch_tiles <= pipe_max_tiles) hipLaunchKernelGGL((blend_walk_kernel<1, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((blend_walk_kernel<1, false>), grid, dim3(256), 0, s, a);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

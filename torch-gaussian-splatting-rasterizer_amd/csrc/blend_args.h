@@ -25,7 +25,44 @@ struct BlendArgs {
     int out_bf16;
     float early_T;
     float sat_scale;      // 2^-25: a pixel is finished once T <= sat_scale * min(Cr, Cg, Cb) (GsrOptions.saturation_rule = 0); 0: only T <= early_T
+    // deferred colours (staged_q2): the scene and camera centre handed to gsr_blend; col_means == nullptr: the ones gsr_preprocess left
+    // in the control block (the library's own stage sequence, and callers of gsr_blend who pass no scene)
+    const float *col_means;
+    const void *col_sh;
+    float col_cc[3];
+    int col_degree, col_sh16;
+    size_t view_stride;     // several views per launch (gridDim.y): bytes between the views' workspace slices ...
+    size_t out_view_stride; // ... and between their frames
 };
+
+// The arguments of view blockIdx.y (the host fills in view 0's): a new value, built field by field — mutating the kernel's argument
+// block in place makes the compiler keep a private copy of it in scratch.
+__device__ __forceinline__ BlendArgs blend_args_of_view(const BlendArgs &a)
+{
+    const size_t o = (size_t)blockIdx.y * a.view_stride;
+    auto at = [](auto *p, size_t off) { return view_at(p, off); };
+    BlendArgs b;
+    b.ranges = at(a.ranges, o);
+    b.cranges = at(a.cranges, o);
+    b.ctiles_x = a.ctiles_x;
+    b.cell_lists = a.cell_lists;
+    b.pval = at(a.pval, o);
+    b.rec = at(a.rec, o);
+    b.ctrl = at(a.ctrl, o);
+    b.out = at(a.out, (size_t)blockIdx.y * a.out_view_stride);
+    b.out_T = a.out_T;
+    b.stats = at(a.stats, o);
+    b.tile_work = at(a.tile_work, o);
+    b.order = at(a.order, o);
+    b.W = a.W; b.H = a.H; b.xlim = a.xlim; b.ylim = a.ylim; b.tiles_x = a.tiles_x;
+    b.row_begin = a.row_begin; b.row_step = a.row_step; b.rows = a.rows;
+    b.layout = a.layout; b.out_bf16 = a.out_bf16; b.early_T = a.early_T; b.sat_scale = a.sat_scale;
+    b.col_means = a.col_means; b.col_sh = a.col_sh;
+    b.col_cc[0] = a.col_cc[0]; b.col_cc[1] = a.col_cc[1]; b.col_cc[2] = a.col_cc[2];
+    b.col_degree = a.col_degree; b.col_sh16 = a.col_sh16;
+    b.view_stride = a.view_stride; b.out_view_stride = a.out_view_stride;
+    return b;
+}
 
 // Has this pixel stopped changing?  (wave-uniformly combined with __all by the kernels.)
 //   - T <= early_T: the caller's threshold; with 0 it fires once T has underflowed to 0.0f, after which alpha*T*rgb = 0 exactly;

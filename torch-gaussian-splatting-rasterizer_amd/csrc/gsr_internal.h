@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "../../include/gsr.h"
 
@@ -94,7 +95,29 @@ struct Workspace {
     int ctiles_x, ctiles_y;  // 32x32 cells = 2x2 tiles
     int hist_blocks;      // row stride of `hist`
     size_t bytes;
+    // Several views through ONE launch sequence (gsr_render_batch): every kernel of the render path is launched with gridDim.y = views
+    // and view v works on the v-th slice of the caller's workspace.  The pointers above are view 0's; slice v lies v * view_stride
+    // bytes further (a slice is a complete one-view workspace: gsr_read_stats reads any of them).
+    int views = 1;
+    size_t view_stride = 0;
 };
+constexpr int MAX_VIEWS = 8;  // views per launch sequence (the cameras travel in the preprocess kernel's argument block)
+
+// p + off bytes, as pointer arithmetic (a round trip through an integer would hide from the compiler that the result still points into the
+// kernel argument's global buffer: flat loads instead of global / scalar ones).
+template <typename T>
+__device__ __forceinline__ T *view_at(T *p, size_t off)
+{
+    using Byte = std::conditional_t<std::is_const<T>::value, const char, char>;
+    return reinterpret_cast<T *>(reinterpret_cast<Byte *>(p) + off);
+}
+__device__ __forceinline__ void *view_at(void *p, size_t off) { return static_cast<char *>(p) + off; }
+// The v-th view's instance of a workspace pointer (v = blockIdx.y; the host passes view 0's).  nullptr stays nullptr.
+template <typename T>
+__device__ __forceinline__ T *view_slice(T *p, size_t view_stride)
+{
+    return p == nullptr ? nullptr : view_at(p, (size_t)blockIdx.y * view_stride);
+}
 
 // Carves `base` (may be nullptr to only size).  Returns total bytes.
 size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max_pairs, Workspace *ws);
@@ -109,7 +132,8 @@ int hip_fail(hipError_t e, const char *what);
     } while (0)
 
 // ---- kernels' host launchers (each returns GSR_OK / GSR_ERR_HIP) --------------------------------
-int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws,
+// cams: ws.views cameras (one frame size); ctrl_reset_words: how much of each view's control block the frame clears
+int launch_preprocess(const GsrScene &scene, const GsrCamera *cams, const GsrOptions &opts, const Workspace &ws,
                       const GsrDebugOut *dbg, int ctrl_reset_words, hipStream_t s);
 int launch_sh_to_rgb(int64_t n, const float *means, const float *sh, const float cc[3], int degree, float *rgb, hipStream_t s);
 int launch_cov3d(int64_t n, const float *log_scales, const float *quats, float *out, hipStream_t s);
@@ -156,8 +180,10 @@ inline bool shard_compact(const GsrOptions &o)
 int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s);
 const uint32_t *tile_lists(const Workspace &ws, const GsrOptions &opts);  // the array ranges[] / cranges[] index after launch_binning (gaussian ids [| tile mask << 28])
 bool blend_reads_cell_lists(const Workspace &ws, const GsrOptions &opts);  // coarse binning: the blend filters the 32x32-cell lists by tile bit itself
+// out_image: view 0's frame, view v's lies v * out_view_stride BYTES further (out_T: single views only).  scene: where deferred
+// colours are evaluated from (single views only); nullptr = what the preprocess left in the workspace's control block
 int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws, const uint32_t *lists, void *out_image,
-                 float *out_T, hipStream_t s);
+                 size_t out_view_stride, float *out_T, const GsrScene *scene, hipStream_t s);
 int launch_blend_stats(FrameCtrl *ctrl, size_t workspace_bytes, hipStream_t s);
 
 // ---- small device helpers -----------------------------------------------------------------------

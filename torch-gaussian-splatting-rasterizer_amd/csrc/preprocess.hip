@@ -50,14 +50,38 @@ __device__ __forceinline__ void record_of(const GeoOut &g, float4 *q0, float4 *q
     *log2_op = log2f(g.op);
 }
 
-// Geometry of gaussian `i`: everything rasterize.py:354-420 computes per gaussian except the colour.
+// The camera-independent half of a gaussian's geometry: what rasterize.py:354-358 reads and derives before any camera is involved.
+struct GeoIn {
+    float C3[3][3];  // cov3D, :357
+    float op;        // sigmoid(opacity_logit), :358
+};
+
+__device__ __forceinline__ GeoIn geometry_load(const GsrScene &sc, int64_t i)
+{
+    GeoIn in;
+    const float ls[3] = {sc.log_scales[3 * i], sc.log_scales[3 * i + 1], sc.log_scales[3 * i + 2]};
+    const float4 q = reinterpret_cast<const float4 *>(sc.quats)[i];
+    const float op_logit = sc.opacity_logit[i];
+    cov3d_of(ls, q, in.C3);                      // :357
+    in.op = 1.0f / (1.0f + expf(-op_logit));    // sigmoid, :358
+    return in;
+}
+
+// Is the gaussian at `p` behind the cull plane of this camera (rasterize.py:377)?  The same expression geometry_view evaluates.
+__device__ __forceinline__ bool culled_by(const Cam &cam, const float p[3])
+{
+    const float *V = cam.V;
+    return ((p[0] * V[2] + p[1] * V[6]) + p[2] * V[10]) + V[14] < GSR_CULL_Z;
+}
+
+// Geometry of gaussian `i` seen from one camera: everything rasterize.py:354-420 computes per gaussian except the colour.  `in` is only
+// read when the gaussian is not culled (or DEBUG): callers may leave it unloaded for a gaussian culled_by() the camera.
 template <bool DEBUG>
-__device__ __forceinline__ GeoOut geometry_one(const GsrScene &sc, const Cam &cam, int compat, int no_cull, int row_begin, int row_step,
-                                               int keep_ref_drawn, const GsrDebugOut &dbg, int64_t i)
+__device__ __forceinline__ GeoOut geometry_view(const float p[3], const GeoIn &in, const Cam &cam, int compat, int no_cull, int row_begin,
+                                                int row_step, int keep_ref_drawn, const GsrDebugOut &dbg, int64_t i)
 {
     GeoOut g;
     g.visible = g.keep_empty = false;
-    const float p[3] = {sc.means[3 * i], sc.means[3 * i + 1], sc.means[3 * i + 2]};
     g.p[0] = p[0]; g.p[1] = p[1]; g.p[2] = p[2];
     const float *V = cam.V, *F = cam.F;
     // project_to_camera_space, rasterize.py:80-86
@@ -79,12 +103,7 @@ __device__ __forceinline__ GeoOut geometry_one(const GsrScene &sc, const Cam &ca
     const float Wf = (float)cam.W, Hf = (float)cam.H;
     const float mx = ((ndc_x + 1.0f) * Wf - 1.0f) / 2.0f, my = ((ndc_y + 1.0f) * Hf - 1.0f) / 2.0f;
 
-    // cov3D, :357
-    const float ls[3] = {sc.log_scales[3 * i], sc.log_scales[3 * i + 1], sc.log_scales[3 * i + 2]};
-    const float4 q = reinterpret_cast<const float4 *>(sc.quats)[i];
-    const float op_logit = sc.opacity_logit[i];
-    float C3[3][3];
-    cov3d_of(ls, q, C3);
+    const float (&C3)[3][3] = in.C3;
 
     // compute_2d_covariance, :201-252
     float c2[4];
@@ -108,7 +127,7 @@ __device__ __forceinline__ GeoOut geometry_one(const GsrScene &sc, const Cam &ca
     const int x_min = clampi((int)tb0 * GSR_TILE, 0, xlim), y_min = clampi((int)tb1 * GSR_TILE, 0, ylim);
     const int x_max = clampi((int)tb2 * GSR_TILE, 0, xlim), y_max = clampi((int)tb3 * GSR_TILE, 0, ylim);
 
-    const float op = 1.0f / (1.0f + expf(-op_logit));  // sigmoid, :358
+    const float op = in.op;
 
     if (DEBUG) {
         if (dbg.cov3d) {
@@ -183,6 +202,21 @@ __device__ __forceinline__ GeoOut geometry_one(const GsrScene &sc, const Cam &ca
     g.tx0 = tx0; g.ty0 = ty0; g.tx1 = tx1; g.ty1 = ty1;
     g.mx = mx; g.my = my; g.sx = sx; g.sy = sy; g.sxy = sxy; g.pthr = pthr; g.op = op;
     return g;
+}
+
+// One gaussian, one camera: load + view.  A gaussian behind the cull plane leaves after its 12-B mean (no debug outputs wanted).
+template <bool DEBUG>
+__device__ __forceinline__ GeoOut geometry_one(const GsrScene &sc, const Cam &cam, int compat, int no_cull, int row_begin, int row_step,
+                                               int keep_ref_drawn, const GsrDebugOut &dbg, int64_t i)
+{
+    const float p[3] = {sc.means[3 * i], sc.means[3 * i + 1], sc.means[3 * i + 2]};
+    if (!DEBUG && culled_by(cam, p)) {
+        GeoOut g;
+        g.visible = g.keep_empty = false;
+        return g;
+    }
+    const GeoIn in = geometry_load(sc, i);
+    return geometry_view<DEBUG>(p, in, cam, compat, no_cull, row_begin, row_step, keep_ref_drawn, dbg, i);
 }
 
 // Colour of gaussian `i` seen from the camera: sh_to_rgb, spherical_harmonics.py:27-73 (rasterize.py:368).
@@ -318,6 +352,67 @@ __global__ __launch_bounds__(PRE_THREADS, !COLOUR ? 8 : (SH16 && !DEBUG) ? 6 : 4
     rec[i] = r;
 }
 
+// Several views per launch (gsr_render_batch; gridDim.y is NOT used here): a thread takes its gaussian through every camera of the
+// batch — the mean is read once, scales / rotation / opacity once (when the first camera that does not cull it comes along) and the
+// 3D covariance and the sigmoid are evaluated once; what depends on the camera is geometry_view, the same code on the same values as
+// the one-view kernel, so every view's records, keys and rects are bit for bit those of a single-view frame.  View v writes into
+// slice v of the workspace (gsr_internal.h, view_slice).  Bytes per gaussian: 44 read once + 64 written per view that sees it.
+struct CamBatch {
+    Cam cam[MAX_VIEWS];
+};
+template <typename T>
+__device__ __forceinline__ T *slice_of(T *p, int v, size_t vstride)
+{
+    return view_at(p, (size_t)v * vstride);
+}
+
+template <bool SH16, bool COLOUR>
+__global__ __launch_bounds__(PRE_THREADS, COLOUR ? 4 : 6) void preprocess_views_kernel(GsrScene sc, CamBatch cams, int views, size_t vstride, int compat, int no_cull,
+                                                                                int row_begin, int row_step, int keep_ref_drawn, GaussRec *__restrict__ rec0,
+                                                                                ushort4 *__restrict__ rect0, uint32_t *__restrict__ rect80,
+                                                                                uint32_t *__restrict__ depth_key0, uint32_t *__restrict__ ctrl_words0,
+                                                                                int ctrl_reset_words, int packed_rect)
+{
+    if (blockIdx.x == 0)
+        for (int v = 0; v < views; ++v) {
+            frame_reset<PRE_THREADS>(slice_of(ctrl_words0, v, vstride), ctrl_reset_words, sc, cams.cam[v]);
+            __syncthreads();
+        }
+    const int64_t i = (int64_t)blockIdx.x * PRE_THREADS + threadIdx.x;
+    if (i >= sc.n) return;
+    const float p[3] = {sc.means[3 * i], sc.means[3 * i + 1], sc.means[3 * i + 2]};
+    const GsrDebugOut none = {};
+    GeoIn in = {};
+    bool loaded = false;
+#pragma unroll 1
+    for (int v = 0; v < views; ++v) {
+        const Cam &cam = cams.cam[v];
+        if (!loaded && !culled_by(cam, p)) { in = geometry_load(sc, i); loaded = true; }
+        const GeoOut g = geometry_view<false>(p, in, cam, compat, no_cull, row_begin, row_step, keep_ref_drawn, none, i);
+        uint32_t *depth_key = slice_of(depth_key0, v, vstride);
+        if (!g.visible) {  // as in preprocess_kernel
+            if (g.keep_empty) {
+                depth_key[i] = g.key;
+                if (packed_rect) slice_of(rect80, v, vstride)[i] = 1u;
+                else slice_of(rect0, v, vstride)[i] = make_ushort4(0, 0, 0, 0);
+            } else {
+                depth_key[i] = KEY_INVALID;
+            }
+            continue;
+        }
+        float rgb[3] = {COLOUR_PENDING, COLOUR_PENDING, COLOUR_PENDING};
+        if constexpr (COLOUR) colour_one<SH16>(sc, cam, i, g.p, rgb);
+        depth_key[i] = g.key;
+        if (packed_rect) slice_of(rect80, v, vstride)[i] = pack_rect8(g);
+        else slice_of(rect0, v, vstride)[i] = make_ushort4((unsigned short)g.tx0, (unsigned short)g.ty0, (unsigned short)g.tx1, (unsigned short)g.ty1);
+        GaussRec r;
+        float log2_op;
+        record_of(g, &r.q0, &r.q1, &log2_op);
+        r.q2 = make_float4(log2_op, rgb[0], rgb[1], rgb[2]);
+        slice_of(rec0, v, vstride)[i] = r;
+    }
+}
+
 // ---- multi-GPU shard (tile rows row_begin, row_begin + row_step, ...) ---------------------------------------------------
 // A rank of G keeps ~1/G of the gaussians, but which ones depends on the camera, so every rank has to look at all N.  Run
 // through the kernel above, nearly every wave still holds a few survivors and walks the whole path with most lanes idle
@@ -362,25 +457,40 @@ __device__ __forceinline__ uint32_t block_append_256(bool flag, uint32_t *s_wave
     return pos;
 }
 
+// Several views per launch (gsr_render_batch): the workgroup takes its span through one camera after the other — what the first view
+// read from HBM the others find in L2 — writing view v's records and runs into slice v of the workspace.
 template <bool SH16, bool COLOUR>
-__global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step,
-                                                               GaussRec *__restrict__ rec, ushort4 *__restrict__ rect,
-                                                               uint32_t *__restrict__ run_key, uint32_t *__restrict__ run_id,
-                                                               uint32_t *__restrict__ run_rect8, uint32_t *__restrict__ run_cnt,
-                                                               uint32_t *__restrict__ ctrl_words, int ctrl_reset_words, int packed_rect)
+__global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, CamBatch cams, int views, size_t vstride, int compat, int no_cull, int row_begin, int row_step,
+                                                               GaussRec *__restrict__ rec0, ushort4 *__restrict__ rect0,
+                                                               uint32_t *__restrict__ run_key0, uint32_t *__restrict__ run_id0,
+                                                               uint32_t *__restrict__ run_rect80, uint32_t *__restrict__ run_cnt0,
+                                                               uint32_t *__restrict__ ctrl_words0, int ctrl_reset_words, int packed_rect)
 {
     __shared__ uint32_t s_cand[SHARD_SPAN];
     __shared__ uint32_t s_id[SHARD_SPAN], s_key[SHARD_SPAN], s_rect8[SHARD_SPAN];
     __shared__ float s_l2op[SHARD_SPAN];
     __shared__ uint32_t s_wave[4], s_ncand, s_nvis;
-    if (blockIdx.x == 0) frame_reset<256>(ctrl_words, ctrl_reset_words, sc, cam);  // as in preprocess_kernel
-    if (threadIdx.x == 0) { s_ncand = 0; s_nvis = 0; }
+    if (blockIdx.x == 0)
+        for (int v = 0; v < views; ++v) {
+            frame_reset<256>(slice_of(ctrl_words0, v, vstride), ctrl_reset_words, sc, cams.cam[v]);  // as in preprocess_kernel
+            __syncthreads();
+        }
     const int64_t base = (int64_t)blockIdx.x * SHARD_SPAN;
+    const int tiles_y = (cams.cam[0].H + GSR_TILE - 1) / GSR_TILE;
+
+#pragma unroll 1
+    for (int v = 0; v < views; ++v) {
+    const Cam &cam = cams.cam[v];
+    GaussRec *__restrict__ rec = slice_of(rec0, v, vstride);
+    ushort4 *__restrict__ rect = slice_of(rect0, v, vstride);
+    uint32_t *__restrict__ run_key = slice_of(run_key0, v, vstride), *__restrict__ run_id = slice_of(run_id0, v, vstride);
+    uint32_t *__restrict__ run_rect8 = slice_of(run_rect80, v, vstride), *__restrict__ run_cnt = slice_of(run_cnt0, v, vstride);
     const float *V = cam.V, *F = cam.F;
     const float Wf = (float)cam.W, Hf = (float)cam.H;
-    const int tiles_y = (cam.H + GSR_TILE - 1) / GSR_TILE;
-
-    // ---- phase 1: the bound.  id = base + r * 256 + thread, appended round by round: the list is in id order ----
+    __syncthreads();  // the previous view's lists have been consumed
+    if (threadIdx.x == 0) { s_ncand = 0; s_nvis = 0; }
+    // what phase 1 reads (from HBM for the first view, from L2 for the others: 24 KB per workgroup; keeping them in registers across the
+    // views costs a wave per SIMD).  id = base + r * 256 + thread, appended round by round: the list is in id order
     float p[SHARD_PER][3], ls[SHARD_PER];
 #pragma unroll
     for (int r = 0; r < SHARD_PER; ++r) {
@@ -391,10 +501,12 @@ __global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, Cam 
         ls[r] = in ? fmaxf(sc.log_scales[3 * i], fmaxf(sc.log_scales[3 * i + 1], sc.log_scales[3 * i + 2])) : 0.0f;
     }
     __syncthreads();
+
+    // ---- phase 1: the bound ----
 #pragma unroll
     for (int r = 0; r < SHARD_PER; ++r) {
         const int64_t i = base + r * 256 + threadIdx.x;
-        // the same expressions as geometry_one (this file is built with -ffp-contract=off)
+        // the same expressions as geometry_view (this file is built with -ffp-contract=off)
         float cm[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) cm[j] = ((p[r][0] * V[0 + j] + p[r][1] * V[4 + j]) + p[r][2] * V[8 + j]) + V[12 + j];
@@ -406,10 +518,10 @@ __global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, Cam 
         const float ndc_x = pt0 * p_w, ndc_y = pt1 * p_w;
         const float mx = ((ndc_x + 1.0f) * Wf - 1.0f) / 2.0f, my = ((ndc_y + 1.0f) * Hf - 1.0f) / 2.0f;
         const float iz = 1.0f / cm[2];
-        const float u = fminf(cam.limx, fmaxf(-cam.limx, cm[0] * iz)), v = fminf(cam.limy, fmaxf(-cam.limy, cm[1] * iz));
+        const float u = fminf(cam.limx, fmaxf(-cam.limx, cm[0] * iz)), vv = fminf(cam.limy, fmaxf(-cam.limy, cm[1] * iz));
         const float jx = cam.fx * iz, jy = cam.fy * iz;
         const float smax = expf(2.0f * ls[r]);
-        const float trb = cam.w_sigma2 * smax * (jx * jx * (1.0f + u * u) + jy * jy * (1.0f + v * v)) + 0.6f;
+        const float trb = cam.w_sigma2 * smax * (jx * jx * (1.0f + u * u) + jy * jy * (1.0f + vv * vv)) + 0.6f;
         const float Rb = 3.0f * sqrtf(1.02f * trb + 0.4f) + 1.5f;
         if (k && Rb < 1.0e8f && fabsf(my) < 1.0e8f) {
             const int lo = max((int)floorf((my - Rb) * 0.0625f), 0), hi = min((int)floorf((my + Rb + 15.0f) * 0.0625f) - 1, tiles_y - 1);
@@ -468,6 +580,7 @@ __global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, Cam 
         run_id[base + j] = (uint32_t)i;
         if (packed_rect) run_rect8[base + j] = s_rect8[j];
     }
+    }  // views
 }
 
 // Workgroup b moves the run of shard_preprocess workgroup b to its place in the compact arrays: position = records of the
@@ -476,9 +589,12 @@ __global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, Cam 
 __global__ __launch_bounds__(256) void shard_compact_kernel(const uint32_t *__restrict__ run_key, const uint32_t *__restrict__ run_id,
                                                             const uint32_t *__restrict__ run_rect8, const uint32_t *__restrict__ run_cnt,
                                                             uint32_t *__restrict__ key, uint32_t *__restrict__ id, uint32_t *__restrict__ rect8,
-                                                            uint32_t *__restrict__ n_records, int packed_rect)
+                                                            uint32_t *__restrict__ n_records, int packed_rect, size_t vstride)
 {
     __shared__ uint32_t scratch[8];
+    run_key = view_slice(run_key, vstride); run_id = view_slice(run_id, vstride); run_rect8 = view_slice(run_rect8, vstride);
+    run_cnt = view_slice(run_cnt, vstride); key = view_slice(key, vstride); id = view_slice(id, vstride); rect8 = view_slice(rect8, vstride);
+    n_records = view_slice(n_records, vstride);
     const int b = (int)blockIdx.x, quads = b >> 2;
     uint32_t mine = 0;
     for (int q = threadIdx.x; q < quads; q += 256) {
@@ -527,15 +643,20 @@ static Cam make_cam(const GsrCamera &c)
     return k;
 }
 
-int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOptions &opts, const Workspace &ws,
+int launch_preprocess(const GsrScene &scene, const GsrCamera *cams, const GsrOptions &opts, const Workspace &ws,
                       const GsrDebugOut *dbg, int ctrl_reset_words, hipStream_t s)
 {
+    const int views = ws.views;
+    if (views < 1 || views > MAX_VIEWS || (dbg && views != 1)) { set_error("bad view count %d", views); return GSR_ERR_BAD_ARG; }
     if (scene.n <= 0) {  // no kernel to carry the frame reset
-        GSR_HIP(hipMemsetAsync(ws.ctrl, 0, 4 * (size_t)ctrl_reset_words, s));
+        for (int v = 0; v < views; ++v)
+            GSR_HIP(hipMemsetAsync(reinterpret_cast<char *>(ws.ctrl) + (size_t)v * ws.view_stride, 0, 4 * (size_t)ctrl_reset_words, s));
         return GSR_OK;
     }
     const unsigned grid = (unsigned)((scene.n + PRE_THREADS - 1) / PRE_THREADS);
-    const Cam k = make_cam(cam);
+    CamBatch kb;
+    for (int v = 0; v < MAX_VIEWS; ++v) kb.cam[v] = make_cam(cams[v < views ? v : 0]);
+    const Cam &k = kb.cam[0];
     GsrDebugOut d;
     memset(&d, 0, sizeof d);
     if (dbg) d = *dbg;
@@ -546,10 +667,15 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
     // >= 48: 0.275 / 0.216, >= 32: 0.359 / 0.202, >= 16: 0.381 / 0.205, never: 0.288 / 0.241.
     const int sh_dense_min = opts.sh_dense_min > 0 ? opts.sh_dense_min : 48;
     const bool colour = opts.colour_stage == 1;  // 0: the blend evaluates a gaussian's colour when a tile first stages it
+    const int keep_drawn = opts.draw_limit > 0 ? 1 : 0;
 #define GSR_LAUNCH_PRE(DBG, H16, COL)                                                                                         \
     hipLaunchKernelGGL((preprocess_kernel<DBG, H16, COL>), dim3(grid), dim3(PRE_THREADS), 0, s, scene, k, opts.reference_compat,     \
-                       opts.no_footprint_cull, opts.tile_row_begin, row_step, opts.draw_limit > 0 ? 1 : 0, ws.rec, ws.rect,     \
+                       opts.no_footprint_cull, opts.tile_row_begin, row_step, keep_drawn, ws.rec, ws.rect,     \
                        ws.rect8[0], ws.key[0], d, reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, packed, sh_dense_min)
+#define GSR_LAUNCH_VIEWS(H16, COL)                                                                                            \
+    hipLaunchKernelGGL((preprocess_views_kernel<H16, COL>), dim3(grid), dim3(PRE_THREADS), 0, s, scene, kb, views, ws.view_stride,     \
+                       opts.reference_compat, opts.no_footprint_cull, opts.tile_row_begin, row_step, keep_drawn, ws.rec, ws.rect,   \
+                       ws.rect8[0], ws.key[0], reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, packed)
     // debug outputs cover every gaussian: for a shard (below) that is a pass of its own, whose other outputs are then
     // overwritten
     if (dbg) { if (h16) GSR_LAUNCH_PRE(true, true, true); else GSR_LAUNCH_PRE(true, false, true); }
@@ -559,19 +685,25 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera &cam, const GsrOpti
         // into them (after shard_compact_kernel has read them); their lengths to blk_sum, idle until the pair count
         uint32_t *run_cnt = ws.blk_sum;
 #define GSR_LAUNCH_SHARD(H16, COL)                                                                                            \
-    hipLaunchKernelGGL((shard_preprocess_kernel<H16, COL>), dim3(sgrid), dim3(256), 0, s, scene, k, opts.reference_compat,             \
+    hipLaunchKernelGGL((shard_preprocess_kernel<H16, COL>), dim3(sgrid), dim3(256), 0, s, scene, kb, views, ws.view_stride, opts.reference_compat,             \
                        opts.no_footprint_cull, opts.tile_row_begin, row_step, ws.rec, ws.rect, ws.key[1], ws.val[1], ws.rect8[1], \
                        run_cnt, reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, packed)
         if (h16) { if (colour) GSR_LAUNCH_SHARD(true, true); else GSR_LAUNCH_SHARD(true, false); }
         else { if (colour) GSR_LAUNCH_SHARD(false, true); else GSR_LAUNCH_SHARD(false, false); }
 #undef GSR_LAUNCH_SHARD
-        hipLaunchKernelGGL(shard_compact_kernel, dim3(sgrid), dim3(256), 0, s, ws.key[1], ws.val[1], ws.rect8[1], run_cnt, ws.key[0], ws.val[0],
-                           ws.rect8[0], &ws.ctrl->n_records, packed);
+        hipLaunchKernelGGL(shard_compact_kernel, dim3(sgrid, (unsigned)views), dim3(256), 0, s, ws.key[1], ws.val[1], ws.rect8[1], run_cnt, ws.key[0], ws.val[0],
+                           ws.rect8[0], &ws.ctrl->n_records, packed, ws.view_stride);
     } else if (!dbg) {
-        if (h16) { if (colour) GSR_LAUNCH_PRE(false, true, true); else GSR_LAUNCH_PRE(false, true, false); }
-        else { if (colour) GSR_LAUNCH_PRE(false, false, true); else GSR_LAUNCH_PRE(false, false, false); }
+        if (views > 1) {
+            if (h16) { if (colour) GSR_LAUNCH_VIEWS(true, true); else GSR_LAUNCH_VIEWS(true, false); }
+            else { if (colour) GSR_LAUNCH_VIEWS(false, true); else GSR_LAUNCH_VIEWS(false, false); }
+        } else {
+            if (h16) { if (colour) GSR_LAUNCH_PRE(false, true, true); else GSR_LAUNCH_PRE(false, true, false); }
+            else { if (colour) GSR_LAUNCH_PRE(false, false, true); else GSR_LAUNCH_PRE(false, false, false); }
+        }
     }
 #undef GSR_LAUNCH_PRE
+#undef GSR_LAUNCH_VIEWS
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

@@ -41,11 +41,12 @@ __device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t n
 template <int THREADS, bool DROP, int ITEMS>
 __global__ __launch_bounds__(THREADS) void radix_hist_kernel(const uint32_t *__restrict__ keys, const uint32_t *n_dev,
                                                              uint32_t n_bound, PassSpec ps, FrameCtrl *ctrl,
-                                                             uint32_t *__restrict__ hist, int hist_blocks)
+                                                             uint32_t *__restrict__ hist, int hist_blocks, size_t vstride)
 {
     constexpr int TILE = THREADS * ITEMS;
     __shared__ uint32_t h[THREADS];
     __shared__ uint32_t s_max;
+    keys = view_slice(keys, vstride); n_dev = view_slice(n_dev, vstride); ctrl = view_slice(ctrl, vstride); hist = view_slice(hist, vstride);
     int shift;
     uint32_t mask;
     if (!resolve_pass(ps, ctrl, &shift, &mask)) return;  // uniform: this depth-sort pass is not needed
@@ -97,11 +98,12 @@ __global__ __launch_bounds__(THREADS) void radix_hist_kernel(const uint32_t *__r
 // The pass-0 rowscan of the depth sort also fixes the plan of the remaining passes (see the header).
 template <int TILE>
 __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t *__restrict__ hist, int hist_blocks, const uint32_t *n_dev,
-                                                            uint32_t n_bound, PassSpec ps, FrameCtrl *ctrl)
+                                                            uint32_t n_bound, PassSpec ps, FrameCtrl *ctrl, size_t vstride)
 {
     __shared__ uint32_t scratch[8];
     int shift;
     uint32_t mask;
+    hist = view_slice(hist, vstride); n_dev = view_slice(n_dev, vstride); ctrl = view_slice(ctrl, vstride);
     if (!resolve_pass(ps, ctrl, &shift, &mask)) return;
     if (ps.dyn_pass == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
         const uint32_t kmax = ctrl->depth_key_max;
@@ -147,12 +149,16 @@ template <int THREADS, bool DROP, int ITEMS, bool HAS_V2, bool INDEX_VALS>
 __global__ __launch_bounds__(THREADS, 4) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint32_t *__restrict__ vals2_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t *__restrict__ vals2_out, const uint32_t *n_dev,
-    uint32_t n_bound, PassSpec ps, const FrameCtrl *ctrl, const uint32_t *__restrict__ hist, int hist_blocks, uint32_t *n_out)
+    uint32_t n_bound, PassSpec ps, const FrameCtrl *ctrl, const uint32_t *__restrict__ hist, int hist_blocks, uint32_t *n_out,
+    size_t vstride)
 {
     using Smem = RadixTileSmem<THREADS, ITEMS, HAS_V2>;
     constexpr int TILE = Smem::TILE;
     __shared__ Smem sm;
     __shared__ uint32_t digit_base[THREADS];  // global position of this tile's run of digit d
+    keys_in = view_slice(keys_in, vstride); vals_in = view_slice(vals_in, vstride); vals2_in = view_slice(vals2_in, vstride);
+    keys_out = view_slice(keys_out, vstride); vals_out = view_slice(vals_out, vstride); vals2_out = view_slice(vals2_out, vstride);
+    n_dev = view_slice(n_dev, vstride); ctrl = view_slice(ctrl, vstride); hist = view_slice(hist, vstride); n_out = view_slice(n_out, vstride);
 
     int shift;
     uint32_t mask;
@@ -253,12 +259,14 @@ static void launch_pass(const uint32_t *kin, const uint32_t *vin, const uint32_t
     constexpr int TILE = THREADS * ITEMS;
     const int nblk = (int)((n_bound + TILE - 1) / TILE);
     const uint32_t nb = (uint32_t)n_bound;
+    const unsigned nv = (unsigned)ws.views;  // gridDim.y: one slice of the workspace per view (gsr_internal.h, view_slice)
+    const size_t vs = ws.view_stride;
 #define GSR_SCATTER(DROP, IDENT)                                                                                                   \
-    hipLaunchKernelGGL((radix_scatter_kernel<THREADS, DROP, ITEMS, HAS_V2, IDENT>), dim3(nblk), dim3(THREADS), 0, s, kin, vin, v2in,   \
-                       kout, vout, v2out, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks, n_out)
-    if (drop) hipLaunchKernelGGL((radix_hist_kernel<THREADS, true, ITEMS>), dim3(nblk), dim3(THREADS), 0, s, kin, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks);
-    else hipLaunchKernelGGL((radix_hist_kernel<THREADS, false, ITEMS>), dim3(nblk), dim3(THREADS), 0, s, kin, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks);
-    hipLaunchKernelGGL(radix_rowscan_kernel<TILE>, dim3(THREADS), dim3(256), 0, s, ws.hist, ws.hist_blocks, cnt_dev, nb, ps, ws.ctrl);
+    hipLaunchKernelGGL((radix_scatter_kernel<THREADS, DROP, ITEMS, HAS_V2, IDENT>), dim3(nblk, nv), dim3(THREADS), 0, s, kin, vin, v2in,   \
+                       kout, vout, v2out, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks, n_out, vs)
+    if (drop) hipLaunchKernelGGL((radix_hist_kernel<THREADS, true, ITEMS>), dim3(nblk, nv), dim3(THREADS), 0, s, kin, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks, vs);
+    else hipLaunchKernelGGL((radix_hist_kernel<THREADS, false, ITEMS>), dim3(nblk, nv), dim3(THREADS), 0, s, kin, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks, vs);
+    hipLaunchKernelGGL(radix_rowscan_kernel<TILE>, dim3(THREADS, nv), dim3(256), 0, s, ws.hist, ws.hist_blocks, cnt_dev, nb, ps, ws.ctrl, vs);
     if (drop) { if (ident) GSR_SCATTER(true, true); else GSR_SCATTER(true, false); }
     else      { if (ident) GSR_SCATTER(false, true); else GSR_SCATTER(false, false); }
 #undef GSR_SCATTER

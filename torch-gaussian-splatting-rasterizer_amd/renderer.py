@@ -191,7 +191,7 @@ def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_r
                  output_layout: int = 0, no_footprint_cull: bool = False, blend_impl: int = 0, draw_limit: int = 0,
                  output_bf16: bool = False, depth_sort_passes: int = 0, keep_flags: bool = False, accum_bf16: bool = False,
                  saturation_rule: int = 0, fine_binning: bool = False, shard_preprocess: int = 0, blend_pipe_tiles: int = 0,
-                 sh_dense_min: int = 0, colour_stage: int = 0, no_order_hint: bool = False) -> GsrOptions:
+                 sh_dense_min: int = 0, colour_stage: int = 0, no_order_hint: bool = False, batch_views: int = 0) -> GsrOptions:
     o = _lib.default_options()
     o.reference_compat = 1 if reference_compat else 0
     o.early_out_T = float(early_out_T)
@@ -212,6 +212,7 @@ def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_r
     o.sh_dense_min = int(sh_dense_min)
     o.no_order_hint = 1 if no_order_hint else 0   # blend launch order by list length alone (default: by what each tile staged last frame)
     o.colour_stage = int(colour_stage)            # 0: sh_to_rgb when a tile first stages the gaussian (blend); 1: for every visible gaussian (preprocess)
+    o.batch_views = int(batch_views)              # render_batch: at most this many views per launch sequence (0: as many as the workspace has slices)
     return o
 
 
@@ -221,10 +222,16 @@ def shard_rows(height: int, begin: int, step: int) -> int:
 
 
 class Rasterizer:
-    """Owns the scratch workspace for one scene and renders frames of it."""
+    """Owns the scratch workspace for one scene and renders frames of it.
 
-    def __init__(self, scene: GaussianScene, max_pairs: Optional[int] = None):
+    `views` > 1 makes the workspace that many slices (each a complete one-view workspace, gsr_workspace_bytes): render_batch /
+    enqueue_batch then put `views` cameras at a time through ONE launch sequence of libgsr (gsr_render_batch: one preprocess that
+    reads the scene once for all of them, one set of sorts, one blend — a quarter of the dispatches per frame at views = 4, each four
+    times better filled).  Frames are bit-identical to single-view renders.  Single frames (render / enqueue) use slice 0."""
+
+    def __init__(self, scene: GaussianScene, max_pairs: Optional[int] = None, views: int = 1):
         self.scene = scene
+        self.views = max(1, min(int(views), _lib.GSR_MAX_BATCH_VIEWS))
         self.max_pairs = min(_lib.GSR_MAX_PAIRS, int(max_pairs) if max_pairs else max(1 << 20, 8 * scene.n))
         # radix passes the depth sort of this scene's frames has needed so far (GsrStats.sort_passes, learned whenever the counters
         # are read): passed as GsrOptions.depth_sort_passes so that the passes a frame does not need are not even enqueued
@@ -232,22 +239,28 @@ class Rasterizer:
         self._ws: Optional[torch.Tensor] = None
         self._last_empty = False   # the last enqueue was a shard without tile rows: no kernel ran, its counters are all zero
         self._chained = False      # frames have been enqueued since the last stats(): the next one keeps their overflow record
+        self._used = 1             # slices that hold unchecked frames (stats() reads them all)
         self._ws_key = None
+        self._slice = 0            # bytes per slice of the workspace
         self.last_stats: Optional[Dict[str, int]] = None
+        self.last_slice_stats: list = []   # stats() per slice: the last view each slice rendered
 
     # -- workspace ------------------------------------------------------------------------------
     def _workspace(self, width: int, height: int) -> torch.Tensor:
-        key = (self.scene.n, width, height, self.max_pairs)
+        key = (self.scene.n, width, height, self.max_pairs, self.views)
         if self._ws is None or self._ws_key != key:
             nbytes = _lib.workspace_bytes(self.scene.n, width, height, self.max_pairs)
             self._ws = None  # free the old one first
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.scene.device)
-            assert self._ws.data_ptr() % 256 == 0
-            # libgsr needs no initialisation (every frame clears its control block); the head is zeroed only so that a
-            # gsr_read_stats BEFORE any frame has run on this workspace reads zeros rather than whatever the allocator left
-            self._ws[: min(4096, nbytes)].zero_()
-            self._ws_key = key
+            self._ws = torch.empty(nbytes * self.views, dtype=torch.uint8, device=self.scene.device)
+            assert self._ws.data_ptr() % 256 == 0 and nbytes % 256 == 0
+            # libgsr needs no initialisation (every frame clears its control block); the head of every slice is zeroed so that a
+            # gsr_read_stats BEFORE any frame has run there reads zeros rather than whatever the allocator left, and so that a
+            # batch chained behind unchecked single frames (keep_flags) finds an empty record in the slices they never used
+            for v in range(self.views):
+                self._ws[v * nbytes: v * nbytes + min(4096, nbytes)].zero_()
+            self._ws_key, self._slice = key, nbytes
             self._chained = self._last_empty = False
+            self._used = 1
         return self._ws
 
     def _out_shape(self, cam: GsrCamera, opts: GsrOptions):
@@ -303,13 +316,27 @@ class Rasterizer:
         previous stats().  Raises GsrPairOverflow / GsrSortPasses when one of them exceeded a bound."""
         if self._ws is None or self._last_empty:  # no workspace yet / an empty shard: no kernel ran, nothing to read
             self.last_stats = {k: 0 for k, _ in GsrStats._fields_ if not k.startswith("_")}
+            self.last_slice_stats = [self.last_stats]
             return self.last_stats
-        st = GsrStats()
-        rc = lib.gsr_read_stats(self._ws.data_ptr(), self._ws.numel(), C.byref(st), _stream_ptr(self.scene.device))
-        self._chained = False  # the next frame starts from a cleared control block
-        self.last_stats = st.as_dict()
-        self.sort_passes = max(self.sort_passes, int(st.sort_passes))  # also when a frame was short of passes: the retry has them
-        check(rc)
+        # every slice that holds unchecked frames (one, unless batches ran): the last view each rendered, its record sticky over all of them
+        per, worst_rc = [], 0
+        for v in range(self._used):
+            st = GsrStats()
+            rc = lib.gsr_read_stats(self._ws.data_ptr() + v * self._slice, self._slice, C.byref(st), _stream_ptr(self.scene.device))
+            per.append(st.as_dict())
+            self.sort_passes = max(self.sort_passes, int(st.sort_passes))  # also when a frame was short of passes: the retry has them
+            if rc == _lib.GSR_ERR_PAIR_OVERFLOW or (rc != 0 and worst_rc != _lib.GSR_ERR_PAIR_OVERFLOW):
+                worst_rc = rc
+        self._chained, self._used = False, 1  # the next frame starts from a cleared control block
+        self.last_slice_stats = per
+        self.last_stats = dict(per[0])
+        if worst_rc:  # what a re-render needs: the worst slice's figures
+            self.last_stats["n_pairs_bbox"] = max(d["n_pairs_bbox"] for d in per)
+            self.last_stats["sort_passes"] = max(d["sort_passes"] for d in per)
+            self.last_stats["overflow"] = 0
+            for d in per:
+                self.last_stats["overflow"] |= d["overflow"]
+        check(worst_rc)
         return self.last_stats
 
     @staticmethod
@@ -359,33 +386,54 @@ class Rasterizer:
             return (img, final_T) if return_T else img
         raise self._incomplete(f"frame still incomplete after {MAX_RETRIES} re-renders", self.last_stats)
 
-    def render_batch(self, cams, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Several views of the resident scene in one call: [B,H,W,3].  Pair buffers and the depth-sort bound are sized on
-        the fly: a view that exceeds one makes the batch re-run with room for the worst view (at most MAX_RETRIES times)."""
-        opts = opts or make_options()
-        if opts.output_layout != 0 or opts.tile_row_step > 1:
-            raise ValueError("render_batch renders whole [H,W,3] frames")
-        cams = list(cams)
-        if not cams:
-            raise ValueError("render_batch needs at least one view")
-        arr = (GsrCamera * len(cams))(*cams)
-        W, H = cams[0].width, cams[0].height
+    def _batch_out(self, cams, opts: GsrOptions, out: Optional[torch.Tensor]):
+        """(out, frame_stride in elements) of a batch: whole frames [B,H,W,3], or with a tile-row shard (output_layout = 2) the
+        strips [B,rows*16,W,3]."""
+        if opts.output_layout == 1:
+            raise ValueError("batches render [H,W,3] frames or shard strips")
+        shape, _ = self._out_shape(cams[0], opts)
+        full = (len(cams),) + tuple(shape)
         dtype = torch.bfloat16 if opts.output_dtype == 1 else torch.float32
         if out is None:
-            out = torch.empty((len(cams), H, W, 3), dtype=dtype, device=self.scene.device)
-        elif tuple(out.shape) != (len(cams), H, W, 3) or out.dtype != dtype or not out.is_contiguous() or not out.is_cuda:
-            raise ValueError(f"out must be a contiguous {dtype} CUDA tensor of shape {(len(cams), H, W, 3)}")
+            out = (torch.zeros if opts.output_layout == 2 else torch.empty)(full, dtype=dtype, device=self.scene.device)
+        elif tuple(out.shape) != full or out.dtype != dtype or not out.is_contiguous() or not out.is_cuda:
+            raise ValueError(f"out must be a contiguous {dtype} CUDA tensor of shape {full}")
+        return out, shape[0] * shape[1] * shape[2]
+
+    def enqueue_batch(self, cams, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Enqueue several views on the current stream, `views` at a time through one launch sequence (gsr_render_batch), with `opts`
+        as given: no host synchronisation, no check of the caller's bounds — like enqueue(), the next stats() speaks for all of them."""
+        opts = opts or make_options()
+        cams = list(cams)
+        if not cams:
+            raise ValueError("a batch needs at least one view")
+        out, stride = self._batch_out(cams, opts, out)
+        if stride == 0:  # a shard that owns no tile row
+            self._last_empty = True
+            return out
+        arr = (GsrCamera * len(cams))(*cams)
+        ws = self._workspace(cams[0].width, cams[0].height)
+        o = GsrOptions.from_buffer_copy(opts)
+        # a slice's first view clears its record (libgsr chains its later views) — unless frames enqueued before are still unchecked
+        o.keep_flags = 1 if (self._chained or opts.keep_flags) else 0
         sc = self.scene.c_struct()
+        check(lib.gsr_render_batch(C.byref(sc), arr, len(cams), C.byref(o), self.max_pairs, ws.data_ptr(), ws.numel(),
+                                   out.data_ptr(), stride, _stream_ptr(self.scene.device)))
+        per_launch = self.views if o.batch_views == 0 else min(self.views, o.batch_views)
+        self._used = max(self._used, min(per_launch, len(cams)))
+        self._chained, self._last_empty = True, False
+        return out
+
+    def render_batch(self, cams, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Several views of the resident scene in one call: [B,H,W,3] (a tile-row shard: [B,rows*16,W,3]), `views` of them per launch
+        sequence.  Pair buffers and the depth-sort bound are sized on the fly: a view that exceeds one makes the batch re-run with
+        room for the worst view (at most MAX_RETRIES times)."""
+        opts = opts or make_options()
+        cams = list(cams)
         unbounded = False
         for _ in range(MAX_RETRIES + 1):
-            ws = self._workspace(W, H)
-            o = GsrOptions.from_buffer_copy(opts if unbounded else self.bounded(opts))
-            # view 0 clears the record, libgsr chains the rest: the counters then speak for every view — and for the frames
-            # enqueue()d on this workspace and not yet checked, whose record view 0 must then keep
-            o.keep_flags = 1 if self._chained else 0
-            check(lib.gsr_render_batch(C.byref(sc), arr, len(cams), C.byref(o), self.max_pairs, ws.data_ptr(), ws.numel(),
-                                       out.data_ptr(), H * W * 3, _stream_ptr(self.scene.device)))
-            self._chained, self._last_empty = True, False
+            o = opts if unbounded else self.bounded(opts)
+            out = self.enqueue_batch(cams, o, out)
             try:
                 self.stats()
                 return out
@@ -444,11 +492,11 @@ class FramesInFlight:
     submit() returns the slot it used; the caller owns the ordering of its output buffers: wait(slot) makes the current
     stream wait for that slot's last frame."""
 
-    def __init__(self, scene: GaussianScene, slots: int = 4, max_pairs: Optional[int] = None):
+    def __init__(self, scene: GaussianScene, slots: int = 4, max_pairs: Optional[int] = None, views: int = 1):
         if slots < 1:
             raise ValueError("slots must be >= 1")
         self.scene = scene
-        self.rasterizers = [Rasterizer(scene, max_pairs=max_pairs) for _ in range(slots)]
+        self.rasterizers = [Rasterizer(scene, max_pairs=max_pairs, views=views) for _ in range(slots)]
         self.streams = [torch.cuda.Stream(device=scene.device) for _ in range(slots)]
         cur = torch.cuda.current_stream(scene.device)
         for st in self.streams:  # the scene upload (and whatever else the caller enqueued) comes first
@@ -479,8 +527,18 @@ class FramesInFlight:
             self.rasterizers[k].enqueue(cam, opts, out=out)
         return k
 
+    def submit_batch(self, cams, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None, slot: Optional[int] = None) -> int:
+        """submit() for several views at once: Rasterizer.enqueue_batch on the next slot's stream (`views` of them per launch sequence)."""
+        k = self._next if slot is None else int(slot)
+        if slot is None:
+            self._next = (self._next + 1) % len(self.rasterizers)
+        with torch.cuda.stream(self.streams[k]):
+            self.rasterizers[k].enqueue_batch(cams, opts, out=out)
+        return k
+
     def render_batch(self, cams, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Rasterizer.render_batch with the views spread round robin over the slots (gsr_render_batch_slots): [B,H,W,3],
+        """Rasterizer.render_batch with the views spread round robin over the slots (gsr_render_batch_slots; with `views` > 1 each
+        slot takes `views` consecutive cameras per launch sequence): [B,H,W,3],
         bit-identical to the single-stream batch.  The current stream waits for every slot before this returns; a view that
         overflows the pair buffers makes the batch re-run with room for it."""
         opts = opts or make_options()
@@ -516,9 +574,12 @@ class FramesInFlight:
             o.keep_flags = 0  # a slot's first view clears its record, libgsr chains the slot's later views
             check(lib.gsr_render_batch_slots(C.byref(sc), arr, len(cams), C.byref(o), r0.max_pairs, ws_arr, wss[0].numel(), st_arr, n,
                                              out.data_ptr(), H * W * 3))
-            used = min(n, len(cams))
-            for r in self.rasterizers[:used]:
-                r._chained, r._last_empty = True, False
+            per_launch = min(r0.views if o.batch_views == 0 else min(r0.views, o.batch_views), len(cams))
+            groups = (len(cams) + per_launch - 1) // per_launch
+            used = min(n, groups)
+            sizes = [min(per_launch, len(cams) - g * per_launch) for g in range(groups)]
+            for k, r in enumerate(self.rasterizers[:used]):
+                r._chained, r._last_empty, r._used = True, False, max(sizes[k::n])  # slices its groups rendered into
             need, short = 0, False
             for k in range(used):
                 try:
