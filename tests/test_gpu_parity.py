@@ -381,6 +381,22 @@ def _rule_cases(G):
     wall = _medium(G, n=300_000, shift=1.6)
     wall[0]["opacity"] = np.full_like(wall[0]["opacity"], 6.0)
     out.append(("opaque wall", wall[0], wall[1]))
+    # colour sums in the denormal range (blend_args.h, pixel_finished): the nearest 30 % of an opaque wall have NO red at all (the
+    # clamp of spherical_harmonics.py:71 leaves exactly 0), the rest a red of 1-3 x 2^-25 — so a pixel's red sum starts growing only
+    # after T has decayed by dozens of orders of magnitude: on this frame ~40 000 pixels end with 0 < Cr < 1e-30, half of them denormal
+    late, cam_l, ocam_l = _medium(G, n=300_000, shift=1.6)
+    late["opacity"] = np.full_like(late["opacity"], 6.0)
+    z = G.orc.preprocess(G.utils.pack_gaussians(late), ocam_l)["cam_means"][:, 2]
+    near = z < np.quantile(z[z >= 0.2], 0.3)
+    f = np.where(near, np.float32(-10.0), np.float32(-0.5 / 0.28209479177387814)).astype(np.float32)
+    k = np.arange(len(z)) % 4 + 1
+    for _ in range(4):
+        f = np.where(~near & (k > 0), np.nextafter(f, np.float32(0), dtype=np.float32), f)
+        k = k - 1
+    late["f_dc_0"] = f
+    for j in range(15):
+        late[f"f_rest_{j}"] = np.zeros_like(late[f"f_rest_{j}"])
+    out.append(("late red (denormal sums)", late, cam_l))
     for name, prefix in (("f2_small.npz", ""), ("f3_edge.npz", "a_"), ("f3_edge.npz", "b_")):
         g = load_golden(name)
         out.append((name + prefix, golden_columns(g), _cams(G, g, prefix)[0]))
@@ -424,6 +440,9 @@ def test_colour_saturation_rule_is_exact(G):
             if not kw:
                 assert torch.equal(b, every) and n1 <= n_every, name
                 saved.append((name, n_every, n1, n0))
+                if name.startswith("late red"):  # the case is what it claims to be
+                    r = b[..., 0]
+                    assert int(((r > 0) & (r < 1e-30)).sum()) > 10_000 and int(((r > 0) & (r < 1.17e-38)).sum()) > 1000
     print()
     for name, n_every, n1, n0 in saved:
         print(f"{name:>22}: evaluated (quadrant, entry) pairs: everything {n_every}, T == 0 rule {n1}, colour rule {n0}")

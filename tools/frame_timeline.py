@@ -11,7 +11,7 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     arg = sys.argv[2] if len(sys.argv) > 2 else "5"
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    starts = [i for i, r in enumerate(rows) if "preprocess_kernel" in r["Kernel_Name"] or "shard_preprocess_kernel" in r["Kernel_Name"]]
+    starts = [i for i, r in enumerate(rows) if "preprocess_kernel" in r["Kernel_Name"] or "preprocess_views_kernel" in r["Kernel_Name"]]
     if arg.startswith("+"):
         s, e = starts[int(arg)], starts[int(arg) + 1]
     else:
@@ -24,7 +24,8 @@ def main():
         gap = (st - prev_end) / 1e3 if prev_end else 0.0
         total += (en - st) / 1e3
         name = r["Kernel_Name"].replace("void ", "").replace("gsr::", "")[:44]
-        print(f"{(st - t0) / 1e3:9.1f} us  dur {(en - st) / 1e3:8.1f}  gap {gap:5.1f}  grid {int(r['Grid_Size_X']):>9d}  wg {r['Workgroup_Size_X']:>4s}  {name}")
+        gy = int(r.get("Grid_Size_Y", 1) or 1)
+        print(f"{(st - t0) / 1e3:9.1f} us  dur {(en - st) / 1e3:8.1f}  gap {gap:5.1f}  grid {int(r['Grid_Size_X']):>9d} x {gy}  wg {r['Workgroup_Size_X']:>4s}  {name}")
         prev_end = en
     print(f"frame span {(prev_end - t0) / 1e3:.1f} us, sum of kernels {total:.1f} us, {e - s} dispatches")
 

@@ -68,13 +68,17 @@ __device__ __forceinline__ BlendArgs blend_args_of_view(const BlendArgs &a)
 //   - T <= early_T: the caller's threshold; with 0 it fires once T has underflowed to 0.0f, after which alpha*T*rgb = 0 exactly;
 //   - T <= 2^-25 min(Cr, Cg, Cb): the colour update is one rounding, C = fma(w, c, C), with w = fl(alpha T) <= T (alpha < 1) and
 //     0 <= c <= 1 (Q7), and C in [2^e, 2^(e+1)) has ulp(C) / 2 = 2^(e-24) > 2^-25 C: so w c <= T < ulp(C) / 2 and the fma returns C
-//     bit for bit — for this entry and, T never growing and C never changing, for every later one.  A channel at exactly 0 gives the
-//     threshold 0 (falls back to the T == 0 rule); a denormal threshold is still a valid (smaller) one.
+//     bit for bit — for this entry and, T never growing and C never changing, for every later one.  The threshold itself must be
+//     exact for that: 2^-25 C is (a power of two times a normal number, normal again) whenever C >= 2^-100; below that — a channel
+//     that is exactly 0 so far, or one that only began to collect colour after T had decayed to ~1e-30 — the product would be rounded
+//     into the denormals, possibly UP (2^-25 * 1.5 * 2^-125 -> 2^-149, where w c can be exactly half an ulp of an odd C and the fma
+//     rounds to even), so there the rule falls back to T == 0 (tests: the "late red" case of test_colour_saturation_rule_is_exact).
 //   - `undrawn`: a pixel whose colour is never stored (outside the frame, or Q1's last column / row) has nothing left to change.
 __device__ __forceinline__ bool pixel_finished(const BlendArgs &a, float T, float Cr, float Cg, float Cb, bool undrawn)
 {
     // sat_scale == 0: the caller's threshold alone (a negative one never fires: "blend every entry", the tests' ground truth)
-    const float thr = a.sat_scale != 0.0f ? fmaxf(a.early_T, a.sat_scale * fminf(fminf(Cr, Cg), Cb)) : a.early_T;
+    const float cmin = fminf(fminf(Cr, Cg), Cb);
+    const float thr = a.sat_scale != 0.0f ? fmaxf(a.early_T, cmin >= 0x1p-100f ? a.sat_scale * cmin : 0.0f) : a.early_T;
     return undrawn | (T <= thr);
 }
 
