@@ -53,6 +53,7 @@ typedef enum GsrStatus {
 #define GSR_EIG_FLOOR 0.1f           /* rasterize.py:172,175 */
 #define GSR_MAX_PAIRS 0xFFFFE000ll   /* largest max_pairs: pairs are indexed in 32 bits, one 4096-pair sort tile of headroom */
 #define GSR_MAX_BATCH_VIEWS 8        /* most views gsr_render_batch puts through one launch sequence */
+#define GSR_BOUNDS_BLOCK 64          /* consecutive gaussians per entry of GsrScene.block_bounds */
 
 /* Camera-independent trained gaussians, exactly the values stored in the INRIA .ply
  * (rasterize.py:98-106,354-358; utils.py:10-31).  Row-major dense arrays. */
@@ -66,6 +67,12 @@ typedef struct GsrScene {
     int32_t sh_degree;          /* 0..3; the reference always evaluates 3 (rasterize.py:368) */
     int32_t sh_dtype;           /* 0 = float32 (the reference's type), 1 = float16 storage (evaluated in fp32; halves the
                                    192-B/gaussian stream that dominates stage 1; ~91 dB vs fp32 coefficients) */
+    const float *block_bounds;  /* optional (NULL = none): [ceil(n / GSR_BOUNDS_BLOCK)][8] from gsr_scene_bounds — per block of
+                                   GSR_BOUNDS_BLOCK consecutive gaussians the box of their means and their largest log-scale.  The
+                                   first kernel of a frame tests every block against the view (cull plane rasterize.py:377, frame, this
+                                   rank's tile rows) and the preprocess skips, BEFORE touching their gaussians' 44 B each, the blocks none
+                                   of whose gaussians can be drawn: a conservative bound, frames are bit-identical with and without.
+                                   Worth having when the arrays are in a spatial order (gsr_scene_order).  16-byte aligned. */
 } GsrScene;
 
 /* One view.  Filled by gsr_camera_setup() or by hand.  All matrices are in the reference's
@@ -269,6 +276,16 @@ int gsr_read_stats(void *workspace, size_t workspace_bytes, GsrStats *out /* [ho
 int gsr_scene_order_bytes(int64_t n, size_t *bytes /* [host] */);
 int gsr_scene_order(int64_t n, const float *means /* [n,3] */, uint32_t *perm_out /* [n] */, void *workspace, size_t workspace_bytes,
                     void *stream);
+
+/* Camera-independent block bounds for GsrScene.block_bounds (no reference counterpart; once per scene, after any reordering):
+ * bounds_out [ceil(n / GSR_BOUNDS_BLOCK)][8] = {min x, min y, min z, max x, max y, max z, max log-scale, 0} over each block of
+ * GSR_BOUNDS_BLOCK consecutive gaussians (a block with a non-finite value gets an unbounded box: never skipped). */
+int gsr_scene_bounds(int64_t n, const float *means /* [n,3] */, const float *log_scales /* [n,3] */, float *bounds_out, void *stream);
+
+/* Which blocks of scene->block_bounds does the preprocess skip for this view (and, with a tile-row shard in opts, this rank)?
+ * dead_out [ceil(n / GSR_BOUNDS_BLOCK)] = 1 where no gaussian of the block can be drawn.  The test the kernels apply, exposed for
+ * tests (every gaussian of a skipped block must fail the reference's own skip guard, rasterize.py:441) and for tooling. */
+int gsr_block_visibility(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, uint8_t *dead_out, void *stream);
 
 /* Stand-alone helpers behind the reference's helper functions (same maths as inside gsr_preprocess). */
 /* sh_to_rgb, spherical_harmonics.py:27-73 */

@@ -214,6 +214,75 @@ def test_views_per_launch_sequence_render_the_single_view_frames(G):
     assert torch.equal(small.render_batch(cams), singles) and small.rasterizers[0].max_pairs > 2048
 
 
+def test_block_culling_is_exact(G):
+    """GsrScene.block_bounds (gsr_scene_bounds; the loaders build them): the preprocess skips, unread, every block of 64 consecutive
+    gaussians that its camera-independent box proves undrawable in a view (cull plane rasterize.py:377, frame, this rank's tile rows).
+    (1) Conservative against the reference-parity intermediates: no gaussian of a skipped block passes the reference's skip guard
+    (rasterize.py:441: bbox area > 0, all conic entries != 0) — Morton and file order, several cameras, whole frames and every rank
+    of 2 / 5 / 8 shards (there: no gaussian of a skipped block has one of the rank's tile rows in its rect).
+    (2) The frame with bounds == the frame without, bit for bit: whole frames, shards through both preprocess kernels, batches of
+    views, progressive prefixes, culling off, non-compat, colours in the preprocess.  (3) It skips something (this scene's gaussians are
+    inflated 3.3x; the 6 M-gaussian bench scene: tools/block_cull_stats.py)."""
+    mk = G.renderer.make_options
+    cols, cam0, _ = _medium(G, n=200_000)
+    W, H = cam0.width, cam0.height
+    fx = G.synthetic.pinhole_focal(W)
+    cams = [G.renderer.make_camera(p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H) for p in G.synthetic.ring_cameras(25)[::6]]
+    # a camera inside the cloud looking outwards (blocks behind the cull plane, blocks straddling it) and one far away (tiny frame footprint)
+    pz = G.synthetic.ring_cameras(25)[3]
+    cams.append(G.renderer.make_camera(pz.qvec, np.asarray(pz.tvec) * 0.05, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H))
+    cams.append(G.renderer.make_camera(pz.qvec, np.asarray(pz.tvec) * 6.0, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H))
+    for spatial in (True, False):
+        scene = G.renderer.GaussianScene.from_columns(cols, spatial_order=spatial)
+        assert (scene.bounds is not None) == spatial   # the loaders build bounds with the spatial order
+        scene.build_bounds()
+        assert scene.bounds.shape == ((scene.n + 63) // 64, 8)
+        bare = G.renderer.GaussianScene({k: scene.t[k] for k in scene.FIELDS})  # the same arrays, no bounds
+        bare.order_t = scene.order_t
+        R, Rb = G.renderer.Rasterizer(scene), G.renderer.Rasterizer(bare)
+        skipped = []
+        for cam in cams:
+            dbg = R.preprocess_debug(cam)   # file order; the debug kernels never skip
+            pb, sg, z = dbg["pixel_bboxes"], dbg["sigmas"], dbg["cam_means"][:, 2]
+            drawn = (z >= 0.2) & ((pb[:, 2] - pb[:, 0]) > 0) & ((pb[:, 3] - pb[:, 1]) > 0) & (sg != 0).all(dim=1)   # rasterize.py:377,:441
+            tb = dbg["tile_bboxes"]
+            if scene.order_t is not None:
+                drawn, tb = drawn[scene.order_t], tb[scene.order_t]
+            pad = (-scene.n) % 64
+            blocks = lambda m: torch.nn.functional.pad(m, (0, pad)).view(-1, 64)
+            dead = scene.blocks_skipped(cam).bool()
+            assert not (blocks(drawn) & dead[:, None]).any(), "a skipped block holds a gaussian the reference draws"
+            skipped.append(float(dead.float().mean()))
+            for step in (2, 5, 8):
+                for begin in range(step):
+                    o = mk(tile_row_begin=begin, tile_row_step=step, output_layout=2)
+                    dead_r = scene.blocks_skipped(cam, o).bool()
+                    # tile rows of the reference rect (an upper bound of the rows the refined rect keeps): [tb1, tb3) in tile units
+                    rows = torch.arange((H + 15) // 16, device=tb.device)
+                    mine = ((rows - begin) % step == 0)[None, :] & (rows[None, :] >= tb[:, 1:2]) & (rows[None, :] < tb[:, 3:4])
+                    reach = drawn & mine.any(dim=1)
+                    assert not (blocks(reach) & dead_r[:, None]).any(), (step, begin)
+                    assert (dead_r | ~dead).all()   # a rank skips at least what the whole frame skips
+            assert torch.equal(R.render(cam), Rb.render(cam))
+            for kw in (dict(tile_row_begin=1, tile_row_step=2, output_layout=2), dict(tile_row_begin=3, tile_row_step=8, output_layout=2),
+                       dict(tile_row_begin=0, tile_row_step=5, output_layout=2), dict(draw_limit=3000), dict(draw_limit=3000, tile_row_begin=1, tile_row_step=2, output_layout=2),
+                       dict(no_footprint_cull=True), dict(reference_compat=False), dict(colour_stage=1)):
+                assert torch.equal(R.render(cam, mk(**kw)), Rb.render(cam, mk(**kw))), kw
+            assert R.last_stats["n_visible"] == Rb.last_stats["n_visible"]
+        R4, Rb4 = G.renderer.Rasterizer(scene, views=4), G.renderer.Rasterizer(bare, views=4)
+        assert torch.equal(R4.render_batch(cams), Rb4.render_batch(cams))
+        o8 = mk(tile_row_begin=5, tile_row_step=8, output_layout=2)
+        assert torch.equal(R4.render_batch(cams, o8), Rb4.render_batch(cams, o8))
+        print(f"\n{'morton' if spatial else 'file'} order: blocks skipped per view " + " ".join(f"{x:.2f}" for x in skipped))
+        if spatial:
+            assert max(skipped) > 0.2 and sum(skipped) / len(skipped) > 0.08, skipped
+    # an unbounded box (a non-finite mean) is never skipped; the frame is unchanged
+    bad = {k: v.copy() for k, v in cols.items()}
+    bad["x"][1000] = np.inf
+    sb = G.renderer.GaussianScene.from_columns(bad, spatial_order=False).build_bounds()
+    assert torch.isinf(sb.bounds[1000 // 64, 3]) and not sb.blocks_skipped(cams[0])[1000 // 64]
+
+
 def test_frames_in_flight_are_bit_identical_to_single_stream(G):
     """renderer.FramesInFlight / gsr_render_batch_slots: independent frames on separate HIP streams, one workspace each
     (bench.py's throughput mode).  Same kernels on the same inputs, so every frame must equal the single-stream render bit

@@ -12,6 +12,8 @@ def main():
     arg = sys.argv[2] if len(sys.argv) > 2 else "5"
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     starts = [i for i, r in enumerate(rows) if "preprocess_kernel" in r["Kernel_Name"] or "preprocess_views_kernel" in r["Kernel_Name"]]
+    if any("block_flags_kernel" in r["Kernel_Name"] for r in rows):  # scenes with block bounds: the flags kernel opens the frame
+        starts = [i for i, r in enumerate(rows) if "block_flags_kernel" in r["Kernel_Name"]]
     if arg.startswith("+"):
         s, e = starts[int(arg)], starts[int(arg) + 1]
     else:

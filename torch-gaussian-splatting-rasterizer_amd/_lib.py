@@ -24,6 +24,7 @@ GSR_ERR_HIP = -4
 GSR_ERR_SORT_PASSES = -5
 GSR_MAX_PAIRS = 0xFFFFE000  # include/gsr.h
 GSR_MAX_BATCH_VIEWS = 8
+GSR_BOUNDS_BLOCK = 64
 
 
 class GsrError(RuntimeError):
@@ -50,6 +51,7 @@ class GsrScene(C.Structure):
         ("sh", C.c_void_p),
         ("sh_degree", C.c_int32),
         ("sh_dtype", C.c_int32),
+        ("block_bounds", C.c_void_p),
     ]
 
 
@@ -119,7 +121,7 @@ class GsrDebugOut(C.Structure):
 EXPORTS = [
     "gsr_version", "gsr_last_error", "gsr_default_options", "gsr_camera_setup", "gsr_workspace_bytes",
     "gsr_preprocess", "gsr_bin_sort", "gsr_blend", "gsr_render_forward", "gsr_read_stats", "gsr_sh_to_rgb", "gsr_cov3d",
-    "gsr_render_batch", "gsr_render_batch_slots", "gsr_scene_order", "gsr_scene_order_bytes", "gsr_project_to_camera_space", "gsr_compute_2d_covariance", "gsr_compute_covering_bbox", "gsr_rasterize_gaussian",
+    "gsr_render_batch", "gsr_render_batch_slots", "gsr_scene_order", "gsr_scene_order_bytes", "gsr_scene_bounds", "gsr_block_visibility", "gsr_project_to_camera_space", "gsr_compute_2d_covariance", "gsr_compute_covering_bbox", "gsr_rasterize_gaussian",
 ]
 
 
@@ -149,6 +151,8 @@ def _load() -> C.CDLL:
     L.gsr_read_stats.argtypes = [vp, sz, C.POINTER(GsrStats), vp]
     L.gsr_scene_order_bytes.argtypes = [i64, C.POINTER(sz)]
     L.gsr_scene_order.argtypes = [i64, vp, vp, vp, sz, vp]
+    L.gsr_scene_bounds.argtypes = [i64, vp, vp, vp, vp]
+    L.gsr_block_visibility.argtypes = [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrOptions), vp, vp]
     L.gsr_sh_to_rgb.argtypes = [i64, vp, vp, C.POINTER(C.c_float), i32, vp, vp]
     L.gsr_cov3d.argtypes = [i64, vp, vp, vp, vp]
     f16 = C.POINTER(C.c_float)

@@ -53,6 +53,7 @@ size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max
     for (int b = 0; b < 2; ++b) ws->key[b] = static_cast<uint32_t *>(take(4 * nn));
     for (int b = 0; b < 2; ++b) ws->val[b] = static_cast<uint32_t *>(take(4 * nn));
     for (int b = 0; b < 2; ++b) ws->rect8[b] = static_cast<uint32_t *>(take(4 * nn));
+    ws->blk_dead = static_cast<unsigned char *>(take((nn + GSR_BOUNDS_BLOCK - 1) / GSR_BOUNDS_BLOCK));  // (with the per-gaussian arrays: stage 1 carves with max_pairs = 0)
     ws->blk_sum = static_cast<uint32_t *>(
         take(4 * ((std::max(nn, (size_t)ws->tiles_x * ws->tiles_y) + EMIT_THREADS - 1) / EMIT_THREADS + 1)));
     ws->hist = static_cast<uint32_t *>(take(4 * 512 * (size_t)ws->hist_blocks));
@@ -64,6 +65,7 @@ size_t carve_workspace(void *base, int64_t n, int width, int height, int64_t max
     ws->tile_order = static_cast<int *>(take(sizeof(int) * order_slots));
     ws->blend_stats = static_cast<uint32_t *>(take(sizeof(uint32_t) * BLEND_STAT_WORDS * order_slots));
     ws->tile_work = static_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)ws->tiles_x * ws->tiles_y));
+
     ws->pair_off = nullptr;
     ws->bytes = off;
     return off;
@@ -214,8 +216,9 @@ static int check_scene(const GsrScene *sc)
     }
     if (sc->sh_degree < 0 || sc->sh_degree > 3) { set_error("sh_degree %d not in 0..3", sc->sh_degree); return GSR_ERR_BAD_ARG; }
     if (sc->sh_dtype != 0 && sc->sh_dtype != 1) { set_error("sh_dtype %d: 0 (float32) or 1 (float16)", sc->sh_dtype); return GSR_ERR_BAD_ARG; }
-    if (reinterpret_cast<uintptr_t>(sc->sh) % 16 != 0 || reinterpret_cast<uintptr_t>(sc->quats) % 16 != 0) {
-        set_error("sh and quats must be 16-byte aligned"); return GSR_ERR_BAD_ARG;
+    if (reinterpret_cast<uintptr_t>(sc->sh) % 16 != 0 || reinterpret_cast<uintptr_t>(sc->quats) % 16 != 0 ||
+        reinterpret_cast<uintptr_t>(sc->block_bounds) % 16 != 0) {
+        set_error("sh, quats and block_bounds must be 16-byte aligned"); return GSR_ERR_BAD_ARG;
     }
     return GSR_OK;
 }
@@ -431,6 +434,22 @@ int gsr_scene_order(int64_t n, const float *means, uint32_t *perm_out, void *wor
         return GSR_ERR_WORKSPACE;
     }
     return launch_scene_order(n, means, perm_out, workspace, static_cast<hipStream_t>(stream));
+}
+
+int gsr_scene_bounds(int64_t n, const float *means, const float *log_scales, float *bounds_out, void *stream)
+{
+    if (n < 0 || n > 0x7FFFFFFF || (n > 0 && (!means || !log_scales || !bounds_out))) { set_error("bad argument"); return GSR_ERR_BAD_ARG; }
+    if (reinterpret_cast<uintptr_t>(bounds_out) % 16 != 0) { set_error("bounds_out must be 16-byte aligned"); return GSR_ERR_BAD_ARG; }
+    return launch_scene_bounds(n, means, log_scales, bounds_out, static_cast<hipStream_t>(stream));
+}
+
+int gsr_block_visibility(const GsrScene *scene, const GsrCamera *cam, const GsrOptions *opts, uint8_t *dead_out, void *stream)
+{
+    int rc = check_scene(scene);
+    if (rc) return rc;
+    if (!cam || !opts || !scene->block_bounds || (scene->n > 0 && !dead_out)) { set_error("null camera / options / block_bounds / output"); return GSR_ERR_BAD_ARG; }
+    if (cam->width <= 0 || cam->height <= 0) { set_error("bad frame size %dx%d", cam->width, cam->height); return GSR_ERR_BAD_ARG; }
+    return launch_block_visibility(*scene, *cam, *opts, dead_out, static_cast<hipStream_t>(stream));
 }
 
 int gsr_sh_to_rgb(int64_t n, const float *means, const float *sh, const float cam_center[3], int32_t degree, float *rgb_out,

@@ -85,6 +85,7 @@ struct Workspace {
     uint2 *ranges;        // [tiles]
     uint2 *cranges;       // [ctiles]  coarse binning: [begin, end) of every 32x32 cell's list in the sorted pair array
     int *tile_order;      // [8 * ceil(tiles_y/8) * tiles_x] blend launch order
+    unsigned char *blk_dead; // [ceil(n / GSR_BOUNDS_BLOCK)] block-level culling: 1 = the preprocess skips the block (preprocess.hip, block_flags_kernel)
     uint32_t *tile_work;  // [tiles] 1 + entries the tile's blend staged in the LAST frame rendered on this workspace (0 / garbage: unknown):
                           // the launch-order hint of the next frame (blend.hip, tile_order_kernel); never cleared, never trusted
     uint32_t *blend_stats; // [tile_order slots][BLEND_STAT_WORDS] per-workgroup counters: plain stores, no atomics (40 k
@@ -135,6 +136,8 @@ int hip_fail(hipError_t e, const char *what);
 // cams: ws.views cameras (one frame size); ctrl_reset_words: how much of each view's control block the frame clears
 int launch_preprocess(const GsrScene &scene, const GsrCamera *cams, const GsrOptions &opts, const Workspace &ws,
                       const GsrDebugOut *dbg, int ctrl_reset_words, hipStream_t s);
+int launch_block_visibility(const GsrScene &scene, const GsrCamera &cam, const GsrOptions &opts, unsigned char *dead, hipStream_t s);
+int launch_scene_bounds(int64_t n, const float *means, const float *log_scales, float *bounds, hipStream_t s);
 int launch_sh_to_rgb(int64_t n, const float *means, const float *sh, const float cc[3], int degree, float *rgb, hipStream_t s);
 int launch_cov3d(int64_t n, const float *log_scales, const float *quats, float *out, hipStream_t s);
 int launch_project(int64_t n, const float *means, const float w2c[16], float *out, hipStream_t s);

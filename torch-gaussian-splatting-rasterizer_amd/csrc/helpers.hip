@@ -39,6 +39,52 @@ __global__ __launch_bounds__(256) void cov3d_kernel(int64_t n, const float *__re
         for (int c = 0; c < 3; ++c) out[9 * i + 3 * r + c] = C3[r][c];
 }
 
+// gsr_scene_bounds: one wave per block of GSR_BOUNDS_BLOCK = 64 consecutive gaussians -> {min xyz, max xyz, max log-scale, 0}.
+// A non-finite mean or scale makes the block's box unbounded (the preprocess then never skips it).
+__global__ __launch_bounds__(256) void scene_bounds_kernel(int64_t n, const float *__restrict__ means, const float *__restrict__ log_scales,
+                                                           float *__restrict__ bounds)
+{
+    static_assert(GSR_BOUNDS_BLOCK == 64, "one wave per block");
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t blk = i >> 6;
+    if (blk * 64 >= n) return;  // wave-uniform
+    const float INF = __builtin_huge_valf();
+    float lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF}, ls = -INF, bad = 0.0f;
+    if (i < n) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float p = means[3 * i + j], s = log_scales[3 * i + j];
+            lo[j] = hi[j] = p;
+            ls = fmaxf(ls, s);
+            if (!(fabsf(p) < INF) || !(fabsf(s) < INF)) bad = 1.0f;  // NaN or Inf
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            lo[j] = fminf(lo[j], __shfl_xor(lo[j], d, 64));
+            hi[j] = fmaxf(hi[j], __shfl_xor(hi[j], d, 64));
+        }
+        ls = fmaxf(ls, __shfl_xor(ls, d, 64));
+        bad = fmaxf(bad, __shfl_xor(bad, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bad != 0.0f) { lo[0] = lo[1] = lo[2] = -INF; hi[0] = hi[1] = hi[2] = INF; ls = INF; }
+        float4 *dst = reinterpret_cast<float4 *>(bounds + 8 * (size_t)blk);
+        dst[0] = make_float4(lo[0], lo[1], lo[2], hi[0]);
+        dst[1] = make_float4(hi[1], hi[2], ls, 0.0f);
+    }
+}
+
+int launch_scene_bounds(int64_t n, const float *means, const float *log_scales, float *bounds, hipStream_t s)
+{
+    if (n <= 0) return GSR_OK;
+    hipLaunchKernelGGL(scene_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, means, log_scales, bounds);
+    GSR_HIP(hipGetLastError());
+    return GSR_OK;
+}
+
 // project_to_camera_space, rasterize.py:80-86
 __global__ __launch_bounds__(256) void project_kernel(int64_t n, const float *__restrict__ means, Mat16 V, float *__restrict__ out)
 {
