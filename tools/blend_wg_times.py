@@ -30,8 +30,8 @@ torch.cuda.synchronize()
 ws = R._workspace(W, H).cpu().numpy()
 off, slots = (int(x) for x in ws[2096:2104].view(np.uint32))      # FrameCtrl.stats_off / stats_slots (gsr_internal.h)
 st = ws[off: off + slots * 32].view(np.uint32).reshape(slots, 8)
-live = st[:, 6] != 0
-t0 = st[live, 5].astype(np.int64); t1 = st[live, 6].astype(np.int64)
+live = st[:, 7] != 0
+t0 = st[live, 6].astype(np.int64); t1 = st[live, 7].astype(np.int64)
 base = t0.min()
 t0 = (t0 - base) / 100.0; t1 = (t1 - base) / 100.0   # us
 dur = t1 - t0

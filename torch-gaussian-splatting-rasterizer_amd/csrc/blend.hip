@@ -1172,12 +1172,11 @@ __global__ __launch_bounds__(256 / QPW, PIPE ? 5 : 8) void blend_walk_kernel(Ble
     }
     if (tid == 0) { stat[4] = fetched; a.tile_work[tile] = fetched + 1u; }
     stat_colour_evals(col_evals, &s_col, stat);
-#ifdef GSR_BLEND_TIMESTAMPS  // (the timestamp build reuses stat[5])
+#ifdef GSR_BLEND_TIMESTAMPS  // (words 6 and 7: the counters gsr_read_stats totals — 0..5 — stay what they are)
     __syncthreads();
     if (tid == 0) {
-        stat[5] = (uint32_t)ts0;
-        stat[6] = (uint32_t)wall_clock64();
-        stat[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID (wave/SIMD/CU/SH/SE), whole register
+        stat[6] = (uint32_t)ts0;
+        stat[7] = (uint32_t)wall_clock64();
     }
 #endif
 #pragma unroll
