@@ -56,7 +56,13 @@ typedef enum GsrStatus {
 #define GSR_BOUNDS_BLOCK 64          /* consecutive gaussians per entry of GsrScene.block_bounds */
 
 /* Camera-independent trained gaussians, exactly the values stored in the INRIA .ply
- * (rasterize.py:98-106,354-358; utils.py:10-31).  Row-major dense arrays. */
+ * (rasterize.py:98-106,354-358; utils.py:10-31).  Row-major dense arrays.
+ * The ORDER of the arrays is the caller's; it decides one thing: gaussians at EXACTLY equal depth (fp32 z_cam) are drawn in array-
+ * index order (the reference's torch.sort, rasterize.py:425, leaves their order undefined; in practice torch's CPU sort keeps file
+ * order).  Arrays in .ply file order therefore reproduce the reference's practical frame bit for bit in its tie order as well; arrays
+ * reordered for speed (gsr_scene_order: what the Python loaders do by default, `spatial_order=False` / `--scene-order file` turn it
+ * off) render the same frame except where two tied gaussians overlap — measured up to ~1e-2 per pixel on scenes with many exact
+ * ties (tools/fuzz_parity.py: 0.0086), ~1e5 tie pairs among the 3.4 M visible gaussians of a 6 M-gaussian scene. */
 typedef struct GsrScene {
     int64_t n;                  /* number of gaussians */
     const float *means;         /* [n,3]  x,y,z */

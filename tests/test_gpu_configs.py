@@ -49,6 +49,14 @@ def _ring_camera(G, W, H, pose=0):
     return G.renderer.make_camera(*args), G.orc.camera(*args)
 
 
+def _in_scene_order(packed, scene):
+    """The packed arrays as `scene` stores them (the loaders' Morton order).  The reference leaves the mutual order of gaussians at
+    EXACTLY equal depth undefined (torch.sort, rasterize.py:425); libgsr and the oracle both resolve such ties by array index, so the
+    oracle is fed the arrays in the scene's order: same gaussians, same tie order — a pass never depends on which tied gaussians
+    happen to overlap (a mip360_like scene of 6 M holds ~1e5 exact fp32 depth ties)."""
+    return packed if scene.order is None else {k: np.ascontiguousarray(v[scene.order]) for k, v in packed.items()}
+
+
 def _oracle_frame(G, packed, ocam):
     pre = G.orc.preprocess(packed, ocam)
     order = G.orc.depth_order(pre["cam_means"])
@@ -63,20 +71,23 @@ def test_configs2_bicycle_full_size(G):
     cam, ocam = _ring_camera(G, W, H)
     mk = G.renderer.make_options
 
-    oimg, _, drawn = _oracle_frame(G, packed, ocam)
-    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(packed))
+    scene = G.renderer.GaussianScene.from_packed(packed)
+    oimg, _, drawn = _oracle_frame(G, _in_scene_order(packed, scene), ocam)
+    R = G.renderer.Rasterizer(scene)
     img = R.render(cam).cpu().numpy()
     st = dict(R.last_stats)
     assert 0 < st["n_visible"] <= drawn and st["overflow"] == 0
     assert_frames_close(img, oimg)
     print(f"\nbicycle fp32: {psnr(img, oimg):.1f} dB vs oracle, stats {st}")
-    del R
+    del R, scene
 
     # fp16 SH storage == the fp16-rounded coefficients evaluated in fp32: compare with the oracle fed exactly those
-    rounded = dict(packed)
-    rounded["sh"] = packed["sh"].astype(np.float16).astype(np.float32)
+    scene_h = G.renderer.GaussianScene.from_packed(packed, sh_half=True)
+    rounded = _in_scene_order(packed, scene_h)
+    rounded["sh"] = rounded["sh"].astype(np.float16).astype(np.float32)
     oimg16, _, _ = _oracle_frame(G, rounded, ocam)
-    Rh = G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(packed, sh_half=True))
+    del rounded
+    Rh = G.renderer.Rasterizer(scene_h)
     half = Rh.render(cam).cpu().numpy()
     assert_frames_close(half, oimg16)
     db_vs_fp32 = psnr(half, oimg)
@@ -105,11 +116,13 @@ def test_configs1_garden_full_size_and_rect_mismatch_count(G):
     N = 5_834_784
     packed = G.utils.pack_gaussians(G.synthetic.mip360_like(N, 360))
     cam, ocam = _ring_camera(G, W, H)
-    oimg, pre, drawn = _oracle_frame(G, packed, ocam)
-    R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_packed(packed))
+    scene = G.renderer.GaussianScene.from_packed(packed)
+    oimg, _, drawn = _oracle_frame(G, _in_scene_order(packed, scene), ocam)
+    R = G.renderer.Rasterizer(scene)
     img = R.render(cam).cpu().numpy()
     assert R.last_stats["n_visible"] <= drawn
     assert_frames_close(img, oimg)
+    pre = G.orc.preprocess(packed, ocam)   # per-gaussian outputs are compared in FILE order (preprocess_debug answers in file order)
     dbg = R.preprocess_debug(cam)
     tb, pb = dbg["tile_bboxes"].cpu().numpy(), dbg["pixel_bboxes"].cpu().numpy()
     del dbg
@@ -242,8 +255,9 @@ def test_configs3_bicycle_camera_set_in_8_tile_row_shards(G):
         frame = plan.assemble([wire[r][i] for r in range(GPUS)])
         assert torch.equal(frame, full[i]), f"camera {i}: the 8-shard frame differs from the unsharded one"
     del wire
+    ordered = _in_scene_order(packed, scene)
     for i in (0, 8, 17):
-        oimg, _, _ = _oracle_frame(G, packed, views[i][1])
+        oimg, _, _ = _oracle_frame(G, ordered, views[i][1])
         img = full[i].cpu().numpy()
         assert_frames_close(img, oimg)
         print(f"camera {i}: {psnr(img, oimg):.1f} dB vs oracle")

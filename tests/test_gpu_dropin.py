@@ -125,6 +125,12 @@ def test_run_rasterization_cli_reproduces_the_reference_frame(mods, tmp_path):
     assert img.shape == (int(g["height"]), int(g["width"]), 3) and os.path.exists(os.path.join(out_dir, "render.png"))
     assert psnr(img, g["image"]) >= 100.0
     assert_frames_close(img, g["image"])
+    # --scene-order file: the .ply's own order in HBM (no exact depth ties in this fixture: the same bits)
+    res = CliRunner().invoke(mods.rasterize.run_rasterization, [
+        "--input_dir", scene_dir, "--trained_model_path", model_dir, "--output_path", out_dir + "_file",
+        "--scene-index", str(int(g["image_id"])), "--scale-factor", "2", "--scene-order", "file"], catch_exceptions=False)
+    assert res.exit_code == 0, res.output
+    assert np.array_equal(np.load(os.path.join(out_dir + "_file", "render.npy")), img)
     # render_scene returns the same frame; a scene index that is not a COLMAP image_id raises KeyError (Q4)
     assert np.array_equal(mods.rasterize.render_scene(scene_dir, model_dir, int(g["image_id"]), 2).cpu().numpy(), img)
     with pytest.raises(KeyError):

@@ -164,12 +164,17 @@ def load_view(input_dir: str, scene_index: int, scale_factor: int):
 
 
 def render_scene(input_dir: str, trained_model_path: str, scene_index: int = 0, scale_factor: int = 2, device: str = "cuda",
-                 reference_compat: bool = True, early_out_T: float = 0.0) -> torch.Tensor:
-    """The render call of the reference (:327-446) as a function: returns the frame [H,W,3] float32 on `device`."""
+                 reference_compat: bool = True, early_out_T: float = 0.0, scene_order: str = "morton") -> torch.Tensor:
+    """The render call of the reference (:327-446) as a function: returns the frame [H,W,3] float32 on `device`.
+    scene_order: "morton" (default) uploads the gaussians along a Morton curve of their means (~10 % faster frames), "file" keeps the
+    .ply's order.  Same frame either way except where gaussians at EXACTLY equal depth overlap: those are drawn in storage order
+    (the reference's torch.sort, :425, leaves them undefined; "file" is what its CPU sort does in practice)."""
+    if scene_order not in ("morton", "file"):
+        raise ValueError("scene_order: 'morton' or 'file'")
     cam, _ = load_view(input_dir, scene_index, scale_factor)
     ply_path = os.path.join(trained_model_path, "point_cloud/iteration_30000/point_cloud.ply")
     logger.info("Fetching trained model from: %s", ply_path)
-    scene = renderer.GaussianScene.from_ply(ply_path, device=device)
+    scene = renderer.GaussianScene.from_ply(ply_path, device=device, spatial_order=scene_order == "morton")
     return renderer.Rasterizer(scene).render(cam, renderer.make_options(reference_compat=reference_compat, early_out_T=early_out_T))
 
 
@@ -179,7 +184,7 @@ def _to_png_array(frame: torch.Tensor) -> np.ndarray:
 
 
 def render_progressive(input_dir: str, trained_model_path: str, output_path: str, scene_index: int = 0, scale_factor: int = 2,
-                       every: int = 1000, framerate: int = 20, device: str = "cuda") -> torch.Tensor:
+                       every: int = 1000, framerate: int = 20, device: str = "cuda", scene_order: str = "morton") -> torch.Tensor:
     """--generate_video (reference :427-429,:448-466): a PNG after gaussian number 1, 1001, 2001, ... of the draw
     order (the reference saves when iteration_step % 1000 == 0, right after drawing), 2 s of padding frames that
     repeat the LAST SAVED frame (the reference re-saves its stale `img`), then ffmpeg if it is installed.
@@ -191,7 +196,7 @@ def render_progressive(input_dir: str, trained_model_path: str, output_path: str
 
     cam, _ = load_view(input_dir, scene_index, scale_factor)
     ply_path = os.path.join(trained_model_path, "point_cloud/iteration_30000/point_cloud.ply")
-    R = renderer.Rasterizer(renderer.GaussianScene.from_ply(ply_path, device=device))
+    R = renderer.Rasterizer(renderer.GaussianScene.from_ply(ply_path, device=device, spatial_order=scene_order == "morton"))
     final = R.render(cam, renderer.make_options(draw_limit=2 ** 31 - 1))  # draw_limit > 0: counters follow the reference's order
     n_drawn = int(R.last_stats["n_visible"])
     img_dir = os.path.join(output_path, "images")
@@ -224,16 +229,20 @@ def render_progressive(input_dir: str, trained_model_path: str, output_path: str
 @click.option("--scene-index", type=int, default=0)
 @click.option("--scale-factor", type=int, default=2)
 @click.option("--generate_video", is_flag=True, type=bool, default=False)
+@click.option("--scene-order", type=click.Choice(["morton", "file"]), default="morton",
+              help="storage order of the gaussians in HBM: along a Morton curve of their means (default, ~10 % faster) or as in the "
+                   ".ply.  Same frame except where gaussians at EXACTLY equal depth overlap (drawn in storage order; the reference "
+                   "leaves their order undefined, 'file' is what its CPU sort does in practice).")
 def run_rasterization(input_dir: str, trained_model_path, output_path: Optional[str], scene_index: int = 0,
-                      scale_factor: int = 2, generate_video: bool = False) -> None:
-    """Same six options as the reference's command (:308-314).  Instead of a matplotlib window the frame is
+                      scale_factor: int = 2, generate_video: bool = False, scene_order: str = "morton") -> None:
+    """Same six options as the reference's command (:308-314) + --scene-order.  Instead of a matplotlib window the frame is
     written to <output_path>/render.npy and render.png (uint8 truncation like the reference's frame dumps, :449)."""
     torch.set_num_threads(max(1, (os.cpu_count() or 2) - 1))
     logger.info("Fetching scenes from: %s", input_dir)
     if generate_video:
-        image = render_progressive(input_dir, trained_model_path, output_path, scene_index, scale_factor)
+        image = render_progressive(input_dir, trained_model_path, output_path, scene_index, scale_factor, scene_order=scene_order)
     else:
-        image = render_scene(input_dir, trained_model_path, scene_index, scale_factor)
+        image = render_scene(input_dir, trained_model_path, scene_index, scale_factor, scene_order=scene_order)
     if output_path:
         from PIL import Image
 
