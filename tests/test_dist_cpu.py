@@ -84,6 +84,30 @@ def _pipeline_worker(rank, world, port, H, W, q):
             ok = ok and len(got) == len(truth) and all(torch.equal(a, b) for a, b in zip(got, truth))
         else:
             ok = ok and not got
+    # batches of `views` frames per submission (a rank renders them through one launch sequence, one gather moves them): 14 frames in
+    # batches of 3 — the last one holds 2 —, with 1 and 2 batches in flight
+    def render_batch(slot, idxs, strips):
+        assert strips.shape[0] == 3 and tuple(strips.shape[1:]) == plan.strip_shape(rank)
+        for j, i in enumerate(idxs):
+            strips[j].copy_(plan.split(truth[i], rank)[: strips.shape[1]])
+
+    for slots in (1, 2):
+        sf = gdist.ShardedFrames(plan, rank, "cpu", slots, render_batch, views=3)
+        got, sizes = [], []
+        batches = [list(range(i, min(i + 3, len(truth)))) for i in range(0, len(truth), 3)]
+        for bt in batches:
+            sizes.append(len(bt))
+            f = sf.submit(bt)
+            if f is not None:
+                got.extend(f[: sizes[len(got) // 3]].clone().unbind(0))
+        while sf.pending:
+            f = sf._finish_oldest()
+            if f is not None:
+                got.extend(f[: sizes[len(got) // 3]].clone().unbind(0))
+        if rank == 0:
+            ok = ok and len(got) == len(truth) and all(torch.equal(a, b) for a, b in zip(got, truth))
+        else:
+            ok = ok and not got
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, ok))

@@ -735,7 +735,7 @@ def test_depth_ties_at_different_positions_follow_the_scene_order(G):
     in_curve = G.renderer.GaussianScene.from_packed(packed)
     R = G.renderer.Rasterizer(in_curve)
     img_curve = R.render(cam).cpu().numpy()
-    assert R.last_stats["n_visible"] > 10_000
+    assert R.last_stats["n_visible"] > 5_000
     ordered = {k: np.ascontiguousarray(v[in_curve.order]) for k, v in packed.items()}
     assert_frames_close(img_curve, G.orc.render(ordered, ocam)[0])
     d = np.abs(img_curve - img_file).max()

@@ -78,38 +78,51 @@ class TileRowPlan:
 
 class FrameGather:
     """Pre-allocated equal-size gather of the strips to rank 0, double-buffered so that the gather of frame k
-    (RCCL, on the communicator's own stream) can overlap the render of frame k+1."""
+    (RCCL, on the communicator's own stream) can overlap the render of frame k+1.
 
-    def __init__(self, plan: TileRowPlan, rank: int, device, dtype=torch.float32, group=None, buffers: int = 2):
-        self.plan, self.rank, self.group = plan, rank, group
-        self.strips = [torch.zeros(plan.padded_shape(), dtype=dtype, device=device) for _ in range(buffers)]
+    `views` > 1: every wire buffer holds the strips of `views` consecutive frames ([views, rows, W, 3]) — what a rank renders through
+    ONE launch sequence (Rasterizer.enqueue_batch) — and ONE collective moves them all (views x the message, the same number of
+    messages per frame batch); rank 0's `frame` is then [views, H, W, 3]."""
+
+    def __init__(self, plan: TileRowPlan, rank: int, device, dtype=torch.float32, group=None, buffers: int = 2, views: int = 1):
+        self.plan, self.rank, self.group, self.views = plan, rank, group, int(views)
+        V = self.views
+        self._strips = [torch.zeros((V,) + plan.padded_shape(), dtype=dtype, device=device) for _ in range(buffers)]
         self.recvs = self._recv_all = self._row_src = None
         self.frame = None
         if rank == 0:
-            # the frame lives in a buffer padded to whole tile rows; `frame` is its first H pixel rows (contiguous)
-            self._frame_padded = torch.zeros((plan.tiles_y * TILE, plan.width, 3), dtype=dtype, device=device)
-            self.frame = self._frame_padded[: plan.height]
+            # the frames live in a buffer padded to whole tile rows; `frame` is its first H pixel rows
+            self._frame_padded = torch.zeros((V, plan.tiles_y * TILE, plan.width, 3), dtype=dtype, device=device)
+            self.frame = self._frame_padded[0, : plan.height] if V == 1 else self._frame_padded[:, : plan.height]
             if plan.world > 1:
                 # one receive buffer per wire buffer, the gather list are views into it, so that de-interleaving the
-                # G strips is ONE index_select (one kernel, one Python call per frame on the root) instead of G copies
-                self._recv_all = [torch.zeros((plan.world,) + plan.padded_shape(), dtype=dtype, device=device) for _ in range(buffers)]
+                # G x V strips is ONE index_select (one kernel, one Python call per batch on the root) instead of G x V copies
+                self._recv_all = [torch.zeros((plan.world, V) + plan.padded_shape(), dtype=dtype, device=device) for _ in range(buffers)]
                 self.recvs = [[ra[r] for r in range(plan.world)] for ra in self._recv_all]
                 t = torch.arange(plan.tiles_y)
-                self._row_src = ((t % plan.world) * plan.max_rows + t // plan.world).to(device)  # frame tile row -> wire row
+                k = torch.arange(V)
+                # (view k, frame tile row t) <- wire row of rank t % world, view k, its row t // world
+                src = ((t % plan.world)[None, :] * V + k[:, None]) * plan.max_rows + (t // plan.world)[None, :]
+                self._row_src = src.reshape(-1).to(device)
+
+    @property
+    def strips(self):
+        return [s[0] for s in self._strips] if self.views == 1 else self._strips
 
     @property
     def strip(self) -> torch.Tensor:
         return self.strips[0]
 
     def own_view(self, buf: int = 0) -> torch.Tensor:
-        """The leading rows of wire buffer `buf` that libgsr writes this rank's strip into."""
+        """The leading rows of wire buffer `buf` that libgsr writes this rank's strip(s) into: [rows, W, 3], or with `views` > 1
+        [views, rows, W, 3] (a strided view: consecutive strips lie a padded strip apart)."""
         k = len(self.plan.rows[self.rank])
-        return self.strips[buf][: k * TILE]
+        return self._strips[buf][0, : k * TILE] if self.views == 1 else self._strips[buf][:, : k * TILE]
 
     def _host_staged(self) -> bool:
         """gloo cannot move device memory: GPU strips go through host buffers (rehearsal of the multi-rank path on a
         box without RCCL peers; the production backend is nccl = RCCL, device to device)."""
-        return self.strips[0].is_cuda and dist.get_backend(self.group) == "gloo"
+        return self._strips[0].is_cuda and dist.get_backend(self.group) == "gloo"
 
     def gather_async(self, buf: int = 0):
         """Start the collective for wire buffer `buf` (every rank calls it once its strip is enqueued on the
@@ -117,28 +130,30 @@ class FrameGather:
         if self.plan.world == 1:
             return (buf, None, None)
         if self._host_staged():
-            send = self.strips[buf].cpu()  # synchronises with the render of this strip
+            send = self._strips[buf].cpu()  # synchronises with the render of this strip
             recv = [torch.empty_like(send) for _ in range(self.plan.world)] if self.rank == 0 else None
             work = dist.gather(send, recv, dst=0, group=self.group, async_op=True)
             return (buf, work, recv)
-        work = dist.gather(self.strips[buf], self.recvs[buf] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
+        work = dist.gather(self._strips[buf], self.recvs[buf] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
         return (buf, work, None)
 
     def finish(self, handle) -> Optional[torch.Tensor]:
-        """Wait for a gather (stream-ordered on GPU backends) and, on rank 0, de-interleave into the frame."""
+        """Wait for a gather (stream-ordered on GPU backends) and, on rank 0, de-interleave into the frame(s)."""
         buf, work, host = handle
         if work is not None:
             work.wait()
         if self.rank != 0:
             return None
         if self.plan.world == 1:
-            return self.plan.assemble([self.strips[buf]], self.frame)
+            for k in range(self.views):
+                self.plan.assemble([self._strips[buf][k]], self._frame_padded[k, : self.plan.height])
+            return self.frame
         if host is not None:
             for dst, src in zip(self.recvs[buf], host):
                 dst.copy_(src)
         row = TILE * self.plan.width * 3
-        torch.index_select(self._recv_all[buf].view(self.plan.world * self.plan.max_rows, row), 0, self._row_src,
-                           out=self._frame_padded.view(self.plan.tiles_y, row))
+        torch.index_select(self._recv_all[buf].view(self.plan.world * self.views * self.plan.max_rows, row), 0, self._row_src,
+                           out=self._frame_padded.view(self.views * self.plan.tiles_y, row))
         return self.frame
 
     def gather(self, buf: int = 0) -> Optional[torch.Tensor]:
@@ -147,7 +162,7 @@ class FrameGather:
 
 
 class ShardedFrames:
-    """The N-GPU frame loop of one rank with `slots` frames in flight.
+    """The N-GPU frame loop of one rank with `slots` frames (or, with `views` > 1, batches of `views` frames) in flight.
 
     Frame f renders on stream f % slots into wire buffer f % slots (`render(slot, cam, strip)` enqueues this rank's strip
     on the CURRENT stream — renderer.FramesInFlight's rasterizer of that slot); its strip is gathered asynchronously (RCCL
@@ -156,18 +171,21 @@ class ShardedFrames:
     which by then has waited for the previous gather out of that buffer and, on rank 0, has de-interleaved the receive
     buffer that gather f will overwrite.  With streams = None (CPU tensors, or one stream) everything runs in program
     order on the current stream; the schedule is the same.
+    With `views` > 1 a submission is a LIST of up to `views` cameras, `render(slot, cams, strips)` gets the [views, rows, W, 3] view of
+    the wire buffer (Rasterizer.enqueue_batch(cams, opts, out=strips[:len(cams)]) renders them through one launch sequence), and one
+    gather moves the batch.
 
-    submit() returns the frame finished by this call on rank 0 (a view of FrameGather.frame, overwritten by the next
-    finish) or None; drain() finishes what is still in flight and returns the last frame."""
+    submit() returns the frame(s) finished by this call on rank 0 (a view of FrameGather.frame, overwritten by the next
+    finish) or None; drain() finishes what is still in flight and returns the last frame(s)."""
 
     def __init__(self, plan: TileRowPlan, rank: int, device, slots: int, render: Callable, dtype=torch.float32, group=None,
-                 streams=None):
+                 streams=None, views: int = 1):
         if slots < 1:
             raise ValueError("slots must be >= 1")
         if streams is not None and len(streams) != slots:
             raise ValueError("one stream per slot")
         self.plan, self.rank, self.device, self.slots = plan, rank, device, int(slots)
-        self.fg = FrameGather(plan, rank, device, dtype=dtype, group=group, buffers=max(2, self.slots))
+        self.fg = FrameGather(plan, rank, device, dtype=dtype, group=group, buffers=max(2, self.slots), views=views)
         self.render, self.streams = render, streams
         self.pending: List = []
         self.frames_submitted = 0

@@ -424,11 +424,14 @@ class Rasterizer:
         shape, _ = self._out_shape(cams[0], opts)
         full = (len(cams),) + tuple(shape)
         dtype = torch.bfloat16 if opts.output_dtype == 1 else torch.float32
+        frame = shape[0] * shape[1] * shape[2]
         if out is None:
             out = (torch.zeros if opts.output_layout == 2 else torch.empty)(full, dtype=dtype, device=self.scene.device)
-        elif tuple(out.shape) != full or out.dtype != dtype or not out.is_contiguous() or not out.is_cuda:
-            raise ValueError(f"out must be a contiguous {dtype} CUDA tensor of shape {full}")
-        return out, shape[0] * shape[1] * shape[2]
+        elif (tuple(out.shape) != full or out.dtype != dtype or not out.is_cuda or (frame and not out[0].is_contiguous())
+              or (len(cams) > 1 and out.stride(0) < frame)):
+            # (consecutive frames may lie further apart than a frame: the strips of a padded wire buffer, dist.FrameGather)
+            raise ValueError(f"out must be a {dtype} CUDA tensor of shape {full} whose frames are contiguous")
+        return out, (out.stride(0) if len(cams) > 1 and frame else frame)
 
     def enqueue_batch(self, cams, opts: Optional[GsrOptions] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Enqueue several views on the current stream, `views` at a time through one launch sequence (gsr_render_batch), with `opts`
@@ -438,7 +441,7 @@ class Rasterizer:
         if not cams:
             raise ValueError("a batch needs at least one view")
         out, stride = self._batch_out(cams, opts, out)
-        if stride == 0:  # a shard that owns no tile row
+        if out.numel() == 0:  # a shard that owns no tile row
             self._last_empty = True
             return out
         arr = (GsrCamera * len(cams))(*cams)
