@@ -182,7 +182,8 @@ typedef struct GsrStats {
     uint64_t wave_entries;  /* (8x8 quadrant, entry) pairs the blend actually evaluated: 64 pixel evaluations each */
     uint64_t fetched_entries; /* list entries the blend staged (<= n_pairs: a saturated tile stops fetching) */
     uint64_t colour_evals;  /* sh_to_rgb evaluations (192-B SH rows read) by the blend: colour_stage = 0 evaluates a gaussian when a tile
-                               first stages it; tiles racing for the same gaussian may each evaluate it (same result).  0 when the
+                               first stages it; tiles racing for the same gaussian may each evaluate it (same result), so this is an
+                               UPPER-BOUND estimate of the gaussians coloured and varies by a few per cent from run to run.  0 when the
                                preprocess evaluated the colours (colour_stage = 1: n_visible evaluations there). */
 } GsrStats;
 
@@ -278,7 +279,9 @@ int gsr_read_stats(void *workspace, size_t workspace_bytes, GsrStats *out /* [ho
  * library draws in array-index order).  perm_out[i] = index, in the caller's arrays, of the gaussian that should be stored i-th: the
  * gaussians along a Morton curve of their means (every axis rank-quantised to 10 bits, bits interleaved, stable).  Gathering all five
  * scene arrays with it before rendering makes the same frames ~10 % faster on MI355X (culled waves, L2 hits).  Once per scene:
- * sixteen radix passes, ~2 ms at 6 M gaussians.  workspace: gsr_scene_order_bytes(n) bytes, 256-B aligned, free afterwards. */
+ * sixteen radix passes; at 6.13 M gaussians the permutation plus the caller's gather of the five arrays take 3.8 ms in a warm process
+ * (the first call of a process also loads this library's code objects: 19 - 71 ms seen).  workspace: gsr_scene_order_bytes(n) bytes,
+ * 256-B aligned, free afterwards. */
 int gsr_scene_order_bytes(int64_t n, size_t *bytes /* [host] */);
 int gsr_scene_order(int64_t n, const float *means /* [n,3] */, uint32_t *perm_out /* [n] */, void *workspace, size_t workspace_bytes,
                     void *stream);

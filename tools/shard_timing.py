@@ -63,3 +63,4 @@ for G in (1, 2, 4, 8) if only is None else (only[0],):
         del fif, single, outs
     print(f"{workload} G={G}: shard ms, one frame in flight: min {min(one):.3f} max {max(one):.3f} | {VIEWS} per launch sequence x {SLOTS} in flight: min {min(many):.3f} "
           f"max {max(many):.3f} | visible/shard {min(vis)}..{max(vis)}  list entries/shard {min(pairs)}..{max(pairs)}", flush=True)
+    print("   per rank, in flight: " + " ".join(f"{x:.3f}" for x in many) + " | one frame: " + " ".join(f"{x:.3f}" for x in one), flush=True)
