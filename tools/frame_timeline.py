@@ -14,10 +14,11 @@ def main():
     starts = [i for i, r in enumerate(rows) if "preprocess_kernel" in r["Kernel_Name"] or "preprocess_views_kernel" in r["Kernel_Name"]]
     if any("block_flags_kernel" in r["Kernel_Name"] for r in rows):  # scenes with block bounds: the flags kernel opens the frame
         starts = [i for i, r in enumerate(rows) if "block_flags_kernel" in r["Kernel_Name"]]
+    span = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # how many frames (launch sequences) to print
     if arg.startswith("+"):
-        s, e = starts[int(arg)], starts[int(arg) + 1]
+        s, e = starts[int(arg)], starts[int(arg) + span]
     else:
-        s, e = starts[-int(arg)], starts[-int(arg) + 1]
+        s, e = starts[-int(arg)], starts[-int(arg) + span] if -int(arg) + span < 0 else len(rows)
     t0 = int(rows[s]["Start_Timestamp"])
     prev_end = None
     total = 0.0
