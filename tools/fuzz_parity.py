@@ -137,6 +137,30 @@ def main():
             cam2 = renderer.make_camera(pose.qvec, np.asarray(pose.tvec) + np.array([0.05, -0.02, 0.1]), *args[2:])
             b = R.render_batch([cam, cam2, cam])
             assert torch.equal(b[0], img) and torch.equal(b[2], img) and torch.equal(b[1], R.render(cam2)), "batch"
+            # several views through ONE launch sequence (gsr_render_batch with K workspace slices): the same frames, also for a
+            # tile-row shard, also with a pair buffer that is too small on entry
+            K = int(rng.choice([2, 3, 4, 8]))
+            img2 = R.render(cam2)
+            views = [cam, cam2, cam, cam2, cam][: int(rng.integers(2, 6))]
+            want = torch.stack([img if v is cam else img2 for v in views])
+            RK = renderer.Rasterizer(scene, max_pairs=int(rng.choice([0, 1000])) or None, views=K)
+            assert torch.equal(RK.render_batch(views), want), f"{K} views per launch sequence differ from single views"
+            so = mk(tile_row_begin=int(rng.integers(0, step)), tile_row_step=step, output_layout=2)
+            assert torch.equal(RK.render_batch(views, so), torch.stack([R.render(v, so) for v in views])), f"{K} views per launch sequence, shard"
+            # block-level culling (GsrScene.block_bounds): the same bits with the bounds, and no skipped block holds a gaussian the
+            # reference would draw (its skip guard, rasterize.py:441, on the reference-parity intermediates)
+            bounded = renderer.GaussianScene.from_packed(packed, sh_degree=degree, spatial_order=False).build_bounds()
+            RB = renderer.Rasterizer(bounded, views=K)
+            assert torch.equal(RB.render(cam), img), "block-level culling changes bits"
+            assert torch.equal(RB.render(cam, so), R.render(cam, so)), "block-level culling changes a shard's bits"
+            assert torch.equal(RB.render_batch(views), want), "block-level culling changes a batch's bits"
+            if n <= 200_000:
+                dbg = R.preprocess_debug(cam)
+                pb, sg = dbg["pixel_bboxes"], dbg["sigmas"]
+                drawn = (dbg["cam_means"][:, 2] >= 0.2) & ((pb[:, 2] - pb[:, 0]) > 0) & ((pb[:, 3] - pb[:, 1]) > 0) & (sg != 0).all(dim=1)
+                dead = bounded.blocks_skipped(cam).bool()
+                per_block = torch.nn.functional.pad(drawn, (0, (-n) % 64)).view(-1, 64)
+                assert not (per_block & dead[:, None]).any(), "a skipped block holds a gaussian the reference draws"
             if degree == 3 and n <= 200_000:
                 pre = orc.preprocess(packed, ocam)
                 dbg = R.preprocess_debug(cam)
@@ -159,6 +183,8 @@ def main():
             # the loader's Morton order: the same frame, bit for bit unless two visible gaussians share a depth exactly
             Rm = renderer.Rasterizer(renderer.GaussianScene.from_packed(packed, sh_degree=degree, spatial_order=True))
             mimg = Rm.render(cam)
+            bare = renderer.GaussianScene({k: Rm.scene.t[k] for k in Rm.scene.FIELDS}, sh_degree=degree)   # the same arrays without block bounds
+            assert torch.equal(renderer.Rasterizer(bare).render(cam), mimg), "block-level culling changes bits (Morton order)"
             # gaussians at EXACTLY equal depth (the generator plants some) are drawn in scene-index order, which the reference
             # leaves undefined: with ties among the visible ones the oracle is fed the arrays in the scene's order (same gaussians, same
             # tie order) — case-seed 1149722072972822031: 20 ties among 40 412 visible, 0.0086 apart from the file-order frame
