@@ -259,11 +259,11 @@ int gsr_render_batch(const GsrScene *scene, const GsrCamera *cams /* [host] */, 
                      int64_t max_pairs, void *workspace, size_t workspace_bytes, void *out_images, int64_t frame_stride,
                      void *stream);
 
-/* The same with n_slots frames in flight: view i is enqueued with workspaces[i % n_slots] on streams[i % n_slots], so that one
- * view's HBM-bound stages overlap another's VALU-bound blend (the library keeps no state; each slot is one more
- * (workspace, stream) pair, every workspace of workspace_bytes).  Frames are bit-identical to gsr_render_batch.  Each
- * workspace's counters afterwards describe the LAST view it rendered; an overflow in any of its views is sticky in them.
- * The caller orders the streams against whatever produced the scene and whatever consumes the frames. */
+/* The same with n_slots batches in flight: with K = the views per launch sequence as above (every workspace of workspace_bytes = K
+ * slices), group g = views g K .. g K + K - 1 is enqueued with workspaces[g % n_slots] on streams[g % n_slots], so that the ramps
+ * and tails of one group's kernels overlap another's (the library keeps no state; each slot is one more (workspace, stream) pair).
+ * Frames are bit-identical to gsr_render_batch.  Each slice's counters afterwards describe the LAST view rendered there; an overflow
+ * in any of them is sticky.  The caller orders the streams against whatever produced the scene and whatever consumes the frames. */
 int gsr_render_batch_slots(const GsrScene *scene, const GsrCamera *cams /* [host] */, int32_t n_cams, const GsrOptions *opts,
                            int64_t max_pairs, void *const *workspaces /* [host] n_slots device pointers */, size_t workspace_bytes,
                            void *const *streams /* [host] n_slots streams */, int32_t n_slots, void *out_images, int64_t frame_stride);
