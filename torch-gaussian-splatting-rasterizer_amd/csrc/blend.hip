@@ -55,11 +55,12 @@ __device__ __forceinline__ T ldg(const T *p, size_t i)
 // entries.  Races are benign by construction: every writer stores the same three values, and a reader accepts the record's
 // colour only when all three channels are non-negative — whatever mix of old and new words it sees (another XCD's L2 may still
 // hold the line from before), it either uses the final values or evaluates them itself.
-// The record's q2 is read and written through relaxed atomics, word by word: the race between the tiles that stage one gaussian is
-// deliberate (see above), and this is how the compiler is told — it may neither cache the words, nor merge or tear the accesses.
-// Scope: wavefront, i.e. plain global loads and stores.  The argument above needs nothing from the hardware beyond "a 32-bit word is
-// read and written whole": a reader that sees a stale word re-evaluates.  Agent scope would set sc1 on every access — on gfx950 each
-// staged entry's colour then bypasses the caches on its way: measured on the bench frame, blend 0.233 -> 0.542 ms.
+// The record's q2 is read and written with ONE 16-B access each, written as asm volatile: the race between the tiles that stage one
+// gaussian is deliberate (see above), and an opaque access is how the compiler is kept out of it — it can neither cache the words nor
+// merge or tear the access.  The argument above needs nothing from the hardware beyond "a 32-bit word is read and written whole": a
+// reader that sees a stale or half-new record re-evaluates.  Measured alternatives (bench frame, blend kernel): the same as four /
+// three relaxed atomics at wavefront scope (plain dword loads and stores: -DGSR_Q2_ATOMICS) 0.235 against 0.228 ms; at agent scope
+// (`sc1` on every access: each staged entry's colour bypasses the caches on its way) 0.542 ms.
 #ifndef GSR_Q2_SCOPE
 #define GSR_Q2_SCOPE __HIP_MEMORY_SCOPE_WAVEFRONT
 #endif
@@ -69,7 +70,14 @@ __device__ __forceinline__ void q2_store(float *w, float v) { __hip_atomic_store
 __device__ __forceinline__ float4 staged_q2(const BlendArgs &a, uint32_t id, uint32_t &evals)
 {
     float *w = reinterpret_cast<float *>(&a.rec[id].q2);
+#ifndef GSR_Q2_ATOMICS
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v q2v;
+    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(q2v) : "v"(w) : "memory");
+    float4 q2 = make_float4(q2v.x, q2v.y, q2v.z, q2v.w);
+#else
     float4 q2 = make_float4(q2_load(w), q2_load(w + 1), q2_load(w + 2), q2_load(w + 3));
+#endif
     if (!(q2.y >= 0.0f && q2.z >= 0.0f && q2.w >= 0.0f)) {
         const FrameCtrl *c = a.ctrl;
         const bool own = a.col_means != nullptr;  // uniform: gsr_blend was handed the scene
@@ -102,7 +110,12 @@ __device__ __forceinline__ float4 staged_q2(const BlendArgs &a, uint32_t id, uin
             else sh_eval_with(p, get, cc, degree, rgb);
         }
         q2.y = rgb[0]; q2.z = rgb[1]; q2.w = rgb[2];
+#ifndef GSR_Q2_ATOMICS
+        q2v.y = q2.y; q2v.z = q2.z; q2v.w = q2.w;
+        asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(w), "v"(q2v) : "memory");
+#else
         q2_store(w + 1, q2.y); q2_store(w + 2, q2.z); q2_store(w + 3, q2.w);  // (w[0], log2 opacity, is the preprocess's and final)
+#endif
         ++evals;
     }
     return q2;
