@@ -267,9 +267,12 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
         if (COARSE) s_fine[tid] = sorted_rect8[r];
     }
     const bool test = cnt > CULL_MIN_TILES;
-    if (test) { s_q0[tid] = rec[g].q0; s_q1[tid] = rec[g].q1; }
+    // (the record gather of a large rect flies while the workgroup scans its counts: it lands in LDS after the scan's barriers)
+    float4 q0v = make_float4(0.f, 0.f, 0.f, 0.f), q1v = q0v;
+    if (test) { q0v = rec[g].q0; q1v = rec[g].q1; }
     uint32_t total;
     s_off[tid] = block_excl_scan_256(cnt, scratch, &total);
+    if (test) { s_q0[tid] = q0v; s_q1[tid] = q1v; }
     s_id[tid] = g;
     s_geo[tid] = (uint32_t)rc.x | ((uint32_t)(rc.z - rc.x) << 16);
     s_first[tid] = test ? -1 - first : first;

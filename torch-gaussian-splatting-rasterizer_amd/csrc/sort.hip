@@ -218,6 +218,8 @@ __global__ __launch_bounds__(THREADS, 4) void radix_scatter_kernel(
     radix_stage(sm, rank, key);
     __syncthreads();
     const uint32_t nvalid = sm.n_valid;
+    // the depth sort's LAST pass (which one that is the frame's plan says) leaves sorted ids and rects: nobody reads the sorted keys
+    const bool write_keys = !(ps.dyn_pass >= 0 && (uint32_t)ps.dyn_pass + 1u == ctrl->sort_passes);
     uint32_t gpos[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(THREADS, 4) void radix_scatter_kernel(
             const uint32_t kk = sm.buf[i];
             const uint32_t d = ((kk - ps.key_base) >> shift) & mask;
             gpos[k] = digit_base[d] + (i - sm.tile_start[d]);
-            keys_out[gpos[k]] = kk;
+            if (write_keys) keys_out[gpos[k]] = kk;
         }
     }
     __syncthreads();
