@@ -11,8 +11,9 @@ mkdir -p "$OUT"
 OUT=$(cd "$OUT" && pwd)
 export TMPDIR=/tmp
 cd /tmp || exit 1
-# one frame in flight: kernels of overlapping frames share the machine, their durations are not attributable
-B="$ROOT/bench.py --workload $WL --no-cpu-baseline --no-psnr --legs= --frames-in-flight 1 ${BENCH_EXTRA:-}"
+# one view per launch sequence, one frame in flight: what bench.py's stage times and roofline object describe (kernels of overlapping
+# frames share the machine, their durations are not attributable; a launch sequence of four views is four frames per kernel)
+B="$ROOT/bench.py --workload $WL --no-cpu-baseline --no-psnr --legs= --frames-in-flight 1 --views-per-launch 1 ${BENCH_EXTRA:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o trace -- python3 $B --steps 30 --warmup 5 > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err" &&
 for spec in "FETCH_SIZE:FETCH_SIZE" "WRITE_SIZE:WRITE_SIZE" \
             "sq:SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
