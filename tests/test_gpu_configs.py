@@ -263,6 +263,15 @@ def test_configs3_bicycle_camera_set_in_8_tile_row_shards(G):
         print(f"camera {i}: {psnr(img, oimg):.1f} dB vs oracle")
 
 
+def test_configs3_batches_of_sharded_frames_over_gloo_ranks_sharing_the_gpu(G):
+    """The same with bench.py's default schedule since round 5: every rank renders its strips of `views` consecutive frames through
+    ONE launch sequence (Rasterizer.enqueue_batch into the padded wire buffer's strided strips) and ONE gather moves the batch
+    (dist.ShardedFrames(views = 2); 7 frames, so the last batch is partial).  Rank 0 compares every frame with its unsharded render."""
+    p = _run_dist_check("gloo", 3, {"GSR_DIST_CHECK_VIEWS": "2", "GSR_DIST_CHECK_SLOTS": "2"})
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "DIST_CHECK_OK" in p.stdout
+
+
 def _run_dist_check(backend, ranks, extra_env=None, timeout=600):
     env = dict(os.environ)
     env["GSR_BENCH_BACKEND"] = backend

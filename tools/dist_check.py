@@ -34,23 +34,39 @@ def main():
     cams = [renderer.make_camera(p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H) for p in synthetic.ring_cameras(25)[:5]]
     plan = gdist.TileRowPlan(H, W, world)
     slots = int(os.environ.get("GSR_DIST_CHECK_SLOTS", "3"))
-    fif = renderer.FramesInFlight(scene, slots=slots)
+    views = int(os.environ.get("GSR_DIST_CHECK_VIEWS", "1"))  # frames per launch sequence and per gather (bench.py --views-per-launch)
+    fif = renderer.FramesInFlight(scene, slots=slots, views=views)
     opts = renderer.make_options(**plan.shard_options(rank))
     fif.set_max_pairs(max(fif.rasterizers[0].fit_pairs(c, opts) for c in cams))
     torch.cuda.synchronize(dev)
-    # bench.py's schedule: `slots` frames in flight, each on its own stream / workspace / wire buffer, gathers asynchronous
-    sf = gdist.ShardedFrames(plan, rank, dev, slots, lambda k, c, strip: fif.rasterizers[k].enqueue(c, opts, out=strip),
-                             streams=fif.streams)
+    # bench.py's schedule: `slots` frames (batches of `views` frames) in flight, each on its own stream / workspace / wire buffer,
+    # gathers asynchronous
     seq = cams + cams[:2]  # 7 frames: every buffer is reused at least once
     frames = []
-    for c in seq:
-        f = sf.submit(c)
+    if views == 1:
+        sf = gdist.ShardedFrames(plan, rank, dev, slots, lambda k, c, strip: fif.rasterizers[k].enqueue(c, opts, out=strip),
+                                 streams=fif.streams)
+        subs, sizes = seq, [1] * len(seq)
+    else:
+        sf = gdist.ShardedFrames(plan, rank, dev, slots, lambda k, cs, strips: fif.rasterizers[k].enqueue_batch(cs, opts, out=strips[: len(cs)]),
+                                 streams=fif.streams, views=views)
+        subs = [seq[i: i + views] for i in range(0, len(seq), views)]   # the last batch is partial
+        sizes = [len(b) for b in subs]
+    done = 0
+
+    def keep(f):
+        nonlocal done
         if rank == 0 and f is not None:
-            frames.append(f.clone())
+            frames.extend(f[: sizes[done]].clone().unbind(0) if views > 1 else [f.clone()])
+        if f is not None or rank != 0:
+            done += 1
+
+    for c in subs:
+        f = sf.submit(c)
+        if f is not None:
+            keep(f)
     while sf.pending:
-        f = sf._finish_oldest()
-        if rank == 0:
-            frames.append(f.clone())
+        keep(sf._finish_oldest())
     for k in range(slots):
         fif.stats(k)
     cams = seq

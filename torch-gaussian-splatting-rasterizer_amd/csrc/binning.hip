@@ -227,13 +227,13 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(uint32_t *__restrict__ 
 // (Round 4 measured the obvious refinement — gaussians of up to four cells, most of them, write their own pairs without search or
 // division, only the larger rects are load-balanced: 46.6 us either way.  The kernel is 13 K workgroups of a ~7-us dependent
 // chain each — counters, ids and rects, scan, stores — eight to a CU: six rounds of latency, not search or store throughput.)
-template <bool PACKED, bool COARSE>
+template <bool PACKED, bool COARSE, typename KeyT>  // KeyT: uint16_t when the keys fit (pair_keys_16bit), else uint32_t
 __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t *__restrict__ id_a, const uint32_t *__restrict__ id_b,
                                                                  const uint32_t *__restrict__ r8_a, const uint32_t *__restrict__ r8_b,
                                                                  const FrameCtrl *ctrl, const ushort4 *__restrict__ rect, Shard sh,
                                                                  int bits_x, int tiles_y, const GaussRec *__restrict__ rec,
                                                                  const uint32_t *blk_off, uint32_t max_pairs,
-                                                                 uint32_t *__restrict__ pkey, uint32_t *__restrict__ pval,
+                                                                 KeyT *__restrict__ pkey, uint32_t *__restrict__ pval,
                                                                  uint32_t draw_limit, Shard tsh, uint32_t *blk_entries /* = blk_off: no __restrict__ on either */,
                                                                  size_t vstride)
 {
@@ -311,13 +311,13 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
                 }
                 const bool hit = mask != 0u && (!tested || footprint_hits_rect(s_q0[lo], s_q1[lo], (float)(tx * 32), (float)(tx * 32 + 31),
                                                                                (float)(ty * 32), (float)(ty * 32 + 31)));
-                pkey[o] = (hit ? (uint32_t)ty << bits_x : culled_row) | (uint32_t)tx;
+                pkey[o] = (KeyT)((hit ? (uint32_t)ty << bits_x : culled_row) | (uint32_t)tx);
                 pval[o] = s_id[lo] | mask << COARSE_ID_BITS;
                 entries += hit ? (uint32_t)__popc(mask) : 0u;
             } else {
                 const bool hit = !tested || footprint_hits_rect(s_q0[lo], s_q1[lo], (float)(tx * 16), (float)(tx * 16 + 15),
                                                                 (float)(ty * 16), (float)(ty * 16 + 15));
-                pkey[o] = (hit ? (uint32_t)ty << bits_x : culled_row) | (uint32_t)tx;
+                pkey[o] = (KeyT)((hit ? (uint32_t)ty << bits_x : culled_row) | (uint32_t)tx);
                 pval[o] = s_id[lo];
             }
         }
@@ -332,29 +332,33 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
     }
 }
 
-__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t *__restrict__ pkey, const uint32_t *n_dev,
+template <typename KeyT>
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const KeyT *__restrict__ pkey, const uint32_t *n_dev,
                                                           uint2 *__restrict__ ranges, int bits_x, int tiles_x, int n_tiles,
                                                           uint32_t stride, size_t vstride)
 {
     pkey = view_slice(pkey, vstride); n_dev = view_slice(n_dev, vstride); ranges = view_slice(ranges, vstride);
-    // four keys per thread from one 16-B load; only the two keys flanking the group are read a second time.
-    // stride = threads in the grid, passed in: gridDim / blockDim would pull in the 256-B hidden kernarg block
+    // PER keys per thread from one 16-B load (four 32-bit keys, eight 16-bit ones); only the two keys flanking the group are read a
+    // second time.  stride = threads in the grid, passed in: gridDim / blockDim would pull in the 256-B hidden kernarg block
+    constexpr int PER = 16 / (int)sizeof(KeyT);
     const uint32_t n = *n_dev;
     const uint32_t maskx = (1u << bits_x) - 1u;
-    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; 4ull * t < n; t += stride) {
-        const uint32_t i = 4u * t;
-        uint32_t k[6];  // k[0] = key before the group, k[1..4] = the group, k[5] = key after it
-        if (i + 4 <= n) {
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; (unsigned long long)PER * t < n; t += stride) {
+        const uint32_t i = (uint32_t)PER * t;
+        uint32_t k[PER + 2];  // k[0] = key before the group, k[1..PER] = the group, k[PER + 1] = key after it
+        if (i + PER <= n) {
             const uint4 v = *reinterpret_cast<const uint4 *>(pkey + i);
-            k[1] = v.x; k[2] = v.y; k[3] = v.z; k[4] = v.w;
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < PER; ++j) k[1 + j] = sizeof(KeyT) == 4 ? w[j] : ((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) k[1 + j] = i + j < n ? pkey[i + j] : KEY_INVALID;
+            for (int j = 0; j < PER; ++j) k[1 + j] = i + j < n ? (uint32_t)pkey[i + j] : KEY_INVALID;
         }
-        k[0] = i > 0 ? pkey[i - 1] : KEY_INVALID;            // KEY_INVALID is no pair key: always a boundary
-        k[5] = i + 4 < n ? pkey[i + 4] : KEY_INVALID;
+        k[0] = i > 0 ? (uint32_t)pkey[i - 1] : KEY_INVALID;            // KEY_INVALID is no pair key: always a boundary
+        k[PER + 1] = i + PER < n ? (uint32_t)pkey[i + PER] : KEY_INVALID;
 #pragma unroll
-        for (int j = 1; j <= 4; ++j) {
+        for (int j = 1; j <= PER; ++j) {
             const uint32_t idx = i + (uint32_t)(j - 1);
             const uint32_t key = k[j];
             const uint32_t tx = key & maskx, tile = (key >> bits_x) * (uint32_t)tiles_x + tx;
@@ -428,14 +432,17 @@ int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s)
 #define GSR_COUNT(P, C) hipLaunchKernelGGL((pair_count_kernel<P, C>), dim3(nblk_count, nv), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
                                            ws.ctrl, ws.rect, C ? csh : sh, ws.blk_sum, ws.ranges, n_tiles, limit, ws.cranges, n_ctiles, ws.ctrl, \
                                            C ? (uint32_t)(reinterpret_cast<const char *>(ws.blk_sum) - reinterpret_cast<const char *>(ws.ctrl)) : 0u, nblk_n, vs)
-#define GSR_EMIT(P, C) hipLaunchKernelGGL((pair_emit_kernel<P, C>), dim3(nblk_n, nv), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
-                                          ws.ctrl, ws.rect, C ? csh : sh, tk.bits_x, tk.grid_y, ws.rec, ws.blk_sum, cap, ws.pkey[0], ws.pval[0], limit, \
+    const bool k16 = pair_keys_16bit(tk.bits_x + tk.bits_y);  // two-byte keys in memory when they fit (sort.hip)
+#define GSR_EMIT_T(P, C, T) hipLaunchKernelGGL((pair_emit_kernel<P, C, T>), dim3(nblk_n, nv), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
+                                          ws.ctrl, ws.rect, C ? csh : sh, tk.bits_x, tk.grid_y, ws.rec, ws.blk_sum, cap, reinterpret_cast<T *>(ws.pkey[0]), ws.pval[0], limit, \
                                           sh, ws.blk_sum, vs)
+#define GSR_EMIT(P, C) do { if (k16) GSR_EMIT_T(P, C, uint16_t); else GSR_EMIT_T(P, C, uint32_t); } while (0)
     if (tk.coarse) GSR_COUNT(true, true); else if (packed_rect) GSR_COUNT(true, false); else GSR_COUNT(false, false);
     hipLaunchKernelGGL(pair_scan_kernel, dim3(1, nv), dim3(1024), 0, s, ws.blk_sum, nblk_n, ws.ctrl, cap, vs);
     if (tk.coarse) GSR_EMIT(true, true); else if (packed_rect) GSR_EMIT(true, false); else GSR_EMIT(false, false);
 #undef GSR_COUNT
 #undef GSR_EMIT
+#undef GSR_EMIT_T
     GSR_HIP(hipGetLastError());
     if (ws.max_pairs <= 0) return GSR_OK;
     // stable sort by cell / tile key; the first pass drops the pairs the emit kernel culled and leaves their count in ctrl
@@ -444,8 +451,10 @@ int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s)
     const int rc = launch_pair_sort(ws, 0, &ws.ctrl->n_slots, 0, tk.bits_x + tk.bits_y, tk.drop_from, n_sorted, &pbuf, s);
     if (rc) return rc;
     const int grid = (int)std::min<int64_t>((ws.max_pairs + 1023) / 1024, 8192);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(grid, nv), dim3(256), 0, s, ws.pkey[pbuf], n_sorted, tk.coarse ? ws.cranges : ws.ranges, tk.bits_x,
-                       tk.grid_x, tk.grid_x * tk.grid_y, (uint32_t)grid * 256u, vs);
+    if (k16) hipLaunchKernelGGL(tile_ranges_kernel<uint16_t>, dim3(grid, nv), dim3(256), 0, s, reinterpret_cast<const uint16_t *>(ws.pkey[pbuf]), n_sorted,
+                                tk.coarse ? ws.cranges : ws.ranges, tk.bits_x, tk.grid_x, tk.grid_x * tk.grid_y, (uint32_t)grid * 256u, vs);
+    else hipLaunchKernelGGL(tile_ranges_kernel<uint32_t>, dim3(grid, nv), dim3(256), 0, s, ws.pkey[pbuf], n_sorted, tk.coarse ? ws.cranges : ws.ranges, tk.bits_x,
+                            tk.grid_x, tk.grid_x * tk.grid_y, (uint32_t)grid * 256u, vs);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

@@ -158,6 +158,9 @@ int launch_scene_order(int64_t n, const float *means, uint32_t *perm_out, void *
 // survivor count in *n_out.  in_buf / *result_buf: which of pkey[]/pval[] holds input / output.
 int launch_pair_sort(const Workspace &ws, int in_buf, const uint32_t *n_dev, int first_bit, int key_bits, uint32_t drop_from,
                      uint32_t *n_out, int *result_buf, hipStream_t s);
+// The pair sort keeps its keys as uint16_t in memory when every key (the culled row included) fits: 6 B per pair instead of 8 through
+// emit, both sort passes and the range scan, all of them bound by HBM.  key_bits = TileKeying.bits_x + bits_y.
+inline bool pair_keys_16bit(int key_bits) { return key_bits <= 16; }
 // Pair keys: (tile row << bits_x) | tile column; culled pairs carry the row `tiles_y` and are dropped from drop_from on.
 struct TileKeying {
     int bits_x, bits_y;   // of the grid the pairs are generated on: tiles, or 32x32 cells when `coarse`

@@ -38,8 +38,11 @@ __device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t n
     return n < n_bound ? n : n_bound;
 }
 
-template <int THREADS, bool DROP, int ITEMS>
-__global__ __launch_bounds__(THREADS) void radix_hist_kernel(const uint32_t *__restrict__ keys, const uint32_t *n_dev,
+// KeyT: how the keys lie in memory — uint32_t, or uint16_t for the pair sort's cell / tile keys when they fit (frames up to 4096 px
+// always do with 32x32 cells: 7 + 8 bits): the sort is bound by HBM, and a pair is then 6 B instead of 8.  Registers and LDS hold
+// 32-bit keys either way.
+template <int THREADS, bool DROP, int ITEMS, typename KeyT = uint32_t>
+__global__ __launch_bounds__(THREADS) void radix_hist_kernel(const KeyT *__restrict__ keys, const uint32_t *n_dev,
                                                              uint32_t n_bound, PassSpec ps, FrameCtrl *ctrl,
                                                              uint32_t *__restrict__ hist, int hist_blocks, size_t vstride)
 {
@@ -145,10 +148,10 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t *__restrict
 // Register budget: two 512-thread workgroups per CU (128 VGPRs; one before: 119 KB of LDS) — depth-sort scatters 54 / 32 us ->
 // 49 / 28 us on the bench frame.  The 256-thread pair sort stays at four per CU: pressed into 96 VGPRs for a fifth it spills
 // and takes 53 instead of 37 us.
-template <int THREADS, bool DROP, int ITEMS, bool HAS_V2, bool INDEX_VALS>
+template <int THREADS, bool DROP, int ITEMS, bool HAS_V2, bool INDEX_VALS, typename KeyT = uint32_t>
 __global__ __launch_bounds__(THREADS, 4) void radix_scatter_kernel(
-    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint32_t *__restrict__ vals2_in,
-    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t *__restrict__ vals2_out, const uint32_t *n_dev,
+    const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, const uint32_t *__restrict__ vals2_in,
+    KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t *__restrict__ vals2_out, const uint32_t *n_dev,
     uint32_t n_bound, PassSpec ps, const FrameCtrl *ctrl, const uint32_t *__restrict__ hist, int hist_blocks, uint32_t *n_out,
     size_t vstride)
 {
@@ -175,15 +178,15 @@ __global__ __launch_bounds__(THREADS, 4) void radix_scatter_kernel(
     // goes out), so that at most four 16-register arrays are live at once
     uint32_t key[ITEMS], rank[ITEMS];
     const bool full = n - base >= (uint32_t)TILE;  // all but the last workgroup: unguarded loads, all in flight together
-    auto load = [&](const uint32_t *__restrict__ src, uint32_t (&v)[ITEMS], uint32_t fill) {
+    auto load = [&](const auto *__restrict__ src, uint32_t (&v)[ITEMS], uint32_t fill) {
         if (full) {
 #pragma unroll
-            for (int r = 0; r < ITEMS; ++r) v[r] = src[base + wave * (64 * ITEMS) + r * 64 + lane];
+            for (int r = 0; r < ITEMS; ++r) v[r] = (uint32_t)src[base + wave * (64 * ITEMS) + r * 64 + lane];
         } else {
 #pragma unroll
             for (int r = 0; r < ITEMS; ++r) {
                 const uint32_t idx = base + wave * (64 * ITEMS) + r * 64 + lane;
-                v[r] = idx < n ? src[idx] : fill;
+                v[r] = idx < n ? (uint32_t)src[idx] : fill;
             }
         }
     };
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(THREADS, 4) void radix_scatter_kernel(
             const uint32_t kk = sm.buf[i];
             const uint32_t d = ((kk - ps.key_base) >> shift) & mask;
             gpos[k] = digit_base[d] + (i - sm.tile_start[d]);
-            if (write_keys) keys_out[gpos[k]] = kk;
+            if (write_keys) keys_out[gpos[k]] = (KeyT)kk;
         }
     }
     __syncthreads();
@@ -253,8 +256,8 @@ __global__ __launch_bounds__(THREADS, 4) void radix_scatter_kernel(
 }
 
 // One pass = hist + rowscan + scatter.  `first` = pass 0 of a sort (may drop, may synthesise the index payload).
-template <int THREADS, int ITEMS, bool HAS_V2>
-static void launch_pass(const uint32_t *kin, const uint32_t *vin, const uint32_t *v2in, uint32_t *kout, uint32_t *vout, uint32_t *v2out,
+template <int THREADS, int ITEMS, bool HAS_V2, typename KeyT = uint32_t>
+static void launch_pass(const KeyT *kin, const uint32_t *vin, const uint32_t *v2in, KeyT *kout, uint32_t *vout, uint32_t *v2out,
                         const uint32_t *cnt_dev, int64_t n_bound, const PassSpec &ps, bool drop, bool ident, uint32_t *n_out,
                         const Workspace &ws, hipStream_t s)
 {
@@ -264,10 +267,10 @@ static void launch_pass(const uint32_t *kin, const uint32_t *vin, const uint32_t
     const unsigned nv = (unsigned)ws.views;  // gridDim.y: one slice of the workspace per view (gsr_internal.h, view_slice)
     const size_t vs = ws.view_stride;
 #define GSR_SCATTER(DROP, IDENT)                                                                                                   \
-    hipLaunchKernelGGL((radix_scatter_kernel<THREADS, DROP, ITEMS, HAS_V2, IDENT>), dim3(nblk, nv), dim3(THREADS), 0, s, kin, vin, v2in,   \
+    hipLaunchKernelGGL((radix_scatter_kernel<THREADS, DROP, ITEMS, HAS_V2, IDENT, KeyT>), dim3(nblk, nv), dim3(THREADS), 0, s, kin, vin, v2in,   \
                        kout, vout, v2out, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks, n_out, vs)
-    if (drop) hipLaunchKernelGGL((radix_hist_kernel<THREADS, true, ITEMS>), dim3(nblk, nv), dim3(THREADS), 0, s, kin, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks, vs);
-    else hipLaunchKernelGGL((radix_hist_kernel<THREADS, false, ITEMS>), dim3(nblk, nv), dim3(THREADS), 0, s, kin, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks, vs);
+    if (drop) hipLaunchKernelGGL((radix_hist_kernel<THREADS, true, ITEMS, KeyT>), dim3(nblk, nv), dim3(THREADS), 0, s, kin, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks, vs);
+    else hipLaunchKernelGGL((radix_hist_kernel<THREADS, false, ITEMS, KeyT>), dim3(nblk, nv), dim3(THREADS), 0, s, kin, cnt_dev, nb, ps, ws.ctrl, ws.hist, ws.hist_blocks, vs);
     hipLaunchKernelGGL(radix_rowscan_kernel<TILE>, dim3(THREADS, nv), dim3(256), 0, s, ws.hist, ws.hist_blocks, cnt_dev, nb, ps, ws.ctrl, vs);
     if (drop) { if (ident) GSR_SCATTER(true, true); else GSR_SCATTER(true, false); }
     else      { if (ident) GSR_SCATTER(false, true); else GSR_SCATTER(false, false); }
@@ -333,7 +336,12 @@ int launch_pair_sort(const Workspace &ws, int in_buf, const uint32_t *n_dev, int
         const int shift = first_bit + bits_pp * p;
         const PassSpec ps = {shift, (1u << std::min(bits_pp, key_bits - shift)) - 1u, 0u, drop_from, -1, 0};
         const bool first = p == 0;
-        launch_pass<PAIR_SORT_THREADS, PAIR_SORT_ITEMS, false>(ws.pkey[cur], ws.pval[cur], nullptr, ws.pkey[cur ^ 1], ws.pval[cur ^ 1], nullptr, cnt_dev,
+        if (pair_keys_16bit(key_bits))  // the keys lie in the first half of each pkey buffer, two bytes each (binning.hip writes them so)
+            launch_pass<PAIR_SORT_THREADS, PAIR_SORT_ITEMS, false, uint16_t>(reinterpret_cast<const uint16_t *>(ws.pkey[cur]), ws.pval[cur], nullptr,
+                                                                            reinterpret_cast<uint16_t *>(ws.pkey[cur ^ 1]), ws.pval[cur ^ 1], nullptr, cnt_dev,
+                                                                            ws.max_pairs, ps, first, false, first ? n_out : nullptr, ws, s);
+        else
+            launch_pass<PAIR_SORT_THREADS, PAIR_SORT_ITEMS, false>(ws.pkey[cur], ws.pval[cur], nullptr, ws.pkey[cur ^ 1], ws.pval[cur ^ 1], nullptr, cnt_dev,
                                                  ws.max_pairs, ps, first, false, first ? n_out : nullptr, ws, s);
         if (first && n_out) cnt_dev = n_out;
         cur ^= 1;
