@@ -89,7 +89,9 @@ __global__ __launch_bounds__(THREADS) void radix_hist_kernel(const KeyT *__restr
         if ((threadIdx.x & 63) == 0) atomicMax(&s_max, kmax);
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * hist_blocks + blockIdx.x] = h[threadIdx.x];
+    // only the digit values the pass has: a 6-bit pass of the 256-thread pair sort would otherwise write (and its scatter read back)
+    // four times the rows — every entry a 64-B sector of its own in this digit-major table
+    if (threadIdx.x <= mask) hist[(size_t)threadIdx.x * hist_blocks + blockIdx.x] = h[threadIdx.x];
     if (ps.dyn_pass == 0 && threadIdx.x == 0) {
         const uint32_t m = s_max;
         // the running maximum only grows: a stale (smaller) value read here costs one redundant atomic, never a wrong result
@@ -122,6 +124,10 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t *__restrict
         ctrl->sort_key_bits = bits;
         ctrl->sort_bits_rest = rest_passes ? (rest + rest_passes - 1) / rest_passes : 0u;
         ctrl->depth_key_max = 0u;  // consumed: a repeated gsr_bin_sort starts from 0 again (the frame clear zeroes it too)
+    }
+    if (blockIdx.x > mask) {  // a digit value this pass does not have (uniform)
+        if (threadIdx.x == 0) ctrl->digit_tot[blockIdx.x] = 0u;
+        return;
     }
     const uint32_t n = load_count(n_dev, n_bound);
     const int nblk = (int)(((unsigned long long)n + TILE - 1) / TILE);
@@ -201,10 +207,11 @@ __global__ __launch_bounds__(THREADS, 4) void radix_scatter_kernel(
 
     radix_tile_layout(sm);
     {  // global digit bases: exclusive scan of the digit totals + this tile's entry of the scanned histogram
-        const uint32_t tot = ctrl->digit_tot[tid];
+        const bool has = (uint32_t)tid <= mask;  // digit values beyond the pass's width do not occur
+        const uint32_t tot = has ? ctrl->digit_tot[tid] : 0u;
         uint32_t all_total;
         const uint32_t gs = block_excl_scan<THREADS>(tot, sm.scratch, &all_total);
-        digit_base[tid] = gs + hist[(size_t)tid * hist_blocks + blockIdx.x];
+        digit_base[tid] = gs + (has ? hist[(size_t)tid * hist_blocks + blockIdx.x] : 0u);
         if (n_out != nullptr && blockIdx.x == 0 && tid == 0) *n_out = all_total;
     }
     __syncthreads();
