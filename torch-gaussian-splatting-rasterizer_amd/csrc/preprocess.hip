@@ -556,16 +556,15 @@ __global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, CamB
     __shared__ uint32_t s_id[SHARD_SPAN], s_key[SHARD_SPAN], s_rect8[SHARD_SPAN];
     __shared__ float s_l2op[SHARD_SPAN];
     __shared__ uint32_t s_wave[4], s_ncand, s_nvis;
-    if (blockIdx.x == 0)
-        for (int v = 0; v < views; ++v) {
-            frame_reset<256>(slice_of(ctrl_words0, v, vstride), ctrl_reset_words, sc, cams.cam[v]);  // as in preprocess_kernel
-            __syncthreads();
-        }
+    // one view per workgroup (blockIdx.y): four views are four times the workgroups, each with ONE three-phase chain, instead of a
+    // quarter of them walking four chains one after the other (phase 1's 24 B per gaussian come from L2 for three of the four)
+    const int v_first = (int)blockIdx.y, v_last = v_first + 1;
+    if (blockIdx.x == 0) frame_reset<256>(slice_of(ctrl_words0, v_first, vstride), ctrl_reset_words, sc, cams.cam[v_first]);  // as in preprocess_kernel
     const int64_t base = (int64_t)blockIdx.x * SHARD_SPAN;
     const int tiles_y = (cams.cam[0].H + GSR_TILE - 1) / GSR_TILE;
 
 #pragma unroll 1
-    for (int v = 0; v < views; ++v) {
+    for (int v = v_first; v < v_last; ++v) {
     const Cam &cam = cams.cam[v];
     GaussRec *__restrict__ rec = slice_of(rec0, v, vstride);
     ushort4 *__restrict__ rect = slice_of(rect0, v, vstride);
@@ -812,7 +811,7 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera *cams, const GsrOpt
         // into them (after shard_compact_kernel has read them); their lengths to blk_sum, idle until the pair count
         uint32_t *run_cnt = ws.blk_sum;
 #define GSR_LAUNCH_SHARD(H16, COL)                                                                                            \
-    hipLaunchKernelGGL((shard_preprocess_kernel<H16, COL>), dim3(sgrid), dim3(256), 0, s, scene, kb, views, ws.view_stride, opts.reference_compat,             \
+    hipLaunchKernelGGL((shard_preprocess_kernel<H16, COL>), dim3(sgrid, (unsigned)views), dim3(256), 0, s, scene, kb, views, ws.view_stride, opts.reference_compat,             \
                        opts.no_footprint_cull, opts.tile_row_begin, row_step, ws.rec, ws.rect, ws.key[1], ws.val[1], ws.rect8[1], \
                        run_cnt, reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, packed, blk_dead)
         if (h16) { if (colour) GSR_LAUNCH_SHARD(true, true); else GSR_LAUNCH_SHARD(true, false); }
