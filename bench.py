@@ -381,9 +381,11 @@ def main():
     out_dtype = torch.bfloat16 if args.bf16_output else torch.float32
     # Views per launch sequence K and batches in flight S (tools/batch_timing.py, bench frame, a different camera every frame /
     # one camera: K x S = 1 x 3: 1789 / 1858 frames/s (rounds 1-4: one view per launch sequence), 2 x 2: 1906 / 1965, 4 x 2: 2016 / 2089,
-    # 8 x 3: 2047 / 2089): 4 x 2.  Tile-row shards of 8: 4 x 3.
-    K = max(1, args.views_per_launch if args.views_per_launch is not None else 4)
-    S = max(1, args.frames_in_flight if args.frames_in_flight is not None else (2 if world == 1 else 3))
+    # 8 x 3: 2047 / 2089; this command line with --steps 20 / 100, two runs each (gpurun_out of round 5, frames/s): 4 x 2: 2023-2075 /
+    # 2120-2174, 5 x 2: 2099-2115 / 2182-2184, 6 x 3: 2129-2133 / 2204-2237, 7 x 3: 2102-2177 / 2146-2235, 8 x 3: 2074-2167 / 2137-2219):
+    # 6 x 3 (18 slices of 0.69 GB).  Tile-row shards of 8: 4 x 3.
+    K = max(1, args.views_per_launch if args.views_per_launch is not None else (6 if world == 1 else 4))
+    S = max(1, args.frames_in_flight if args.frames_in_flight is not None else 3)
     fif = renderer.FramesInFlight(scene, slots=S, views=K)
     R = fif.rasterizers[0]
     state = {"f": 0, "b": 0}
