@@ -545,7 +545,7 @@ __device__ __forceinline__ uint32_t block_append_256(bool flag, uint32_t *s_wave
 // Several views per launch (gsr_render_batch): the workgroup takes its span through one camera after the other — what the first view
 // read from HBM the others find in L2 — writing view v's records and runs into slice v of the workspace.
 template <bool SH16, bool COLOUR>
-__global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, CamBatch cams, int views, size_t vstride, int compat, int no_cull, int row_begin, int row_step,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void shard_preprocess_kernel(GsrScene sc, CamBatch cams, int views, size_t vstride, int compat, int no_cull, int row_begin, int row_step,
                                                                GaussRec *__restrict__ rec0, ushort4 *__restrict__ rect0,
                                                                uint32_t *__restrict__ run_key0, uint32_t *__restrict__ run_id0,
                                                                uint32_t *__restrict__ run_rect80, uint32_t *__restrict__ run_cnt0,
@@ -553,9 +553,13 @@ __global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, CamB
                                                                const unsigned char *__restrict__ blk_dead0)
 {
     __shared__ uint32_t s_cand[SHARD_SPAN];
-    __shared__ uint32_t s_id[SHARD_SPAN], s_key[SHARD_SPAN], s_rect8[SHARD_SPAN];
+    __shared__ uint32_t s_key[SHARD_SPAN], s_rect8[SHARD_SPAN];
+    // the visible list's ids overwrite the candidate list in place: phase 2 reads s_cand[c0 + t] before the barriers of its append and
+    // writes s_id[pos] after them, pos <= c0 + t — only entries every thread has already read.  16 KB + a few words of LDS per
+    // workgroup instead of 20 KB + a few words, which was one workgroup per CU too many for eight (7 waves per SIMD).
+    uint32_t *const s_id = s_cand;
     __shared__ float s_l2op[SHARD_SPAN];
-    __shared__ uint32_t s_wave[4], s_ncand, s_nvis;
+    __shared__ uint32_t s_wave[4], s_scan[8], s_nvis;
     // one view per workgroup (blockIdx.y): four views are four times the workgroups, each with ONE three-phase chain, instead of a
     // quarter of them walking four chains one after the other (phase 1's 24 B per gaussian come from L2 for three of the four)
     const int v_first = (int)blockIdx.y, v_last = v_first + 1;
@@ -573,32 +577,43 @@ __global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, CamB
     const float *V = cam.V, *F = cam.F;
     const float Wf = (float)cam.W, Hf = (float)cam.H;
     __syncthreads();  // the previous view's lists have been consumed
-    if (threadIdx.x == 0) { s_ncand = 0; s_nvis = 0; }
-    // what phase 1 reads (from HBM for the first view, from L2 for the others: 24 KB per workgroup; keeping them in registers across the
-    // views costs a wave per SIMD).  id = base + r * 256 + thread, appended round by round: the list is in id order
+    if (threadIdx.x == 0) s_nvis = 0;
+    // what phase 1 reads: a thread takes FOUR CONSECUTIVE gaussians, ids base + 4 t + r — 48 contiguous bytes of means and of
+    // log-scales, three 16-B loads each when the arrays are 16-B aligned (a wave: 3 KB in a row) — so that ONE workgroup scan of the
+    // threads' candidate counts puts the list in id order (round 5; before: ids base + 256 r + t, four stable appends of two barriers
+    // each).  The four lie in one block of GSR_BOUNDS_BLOCK: one flag per thread.
     float p[SHARD_PER][3], ls[SHARD_PER];
     const unsigned char *blk_dead = blk_dead0 != nullptr ? slice_of(blk_dead0, v, vstride) : nullptr;
-    unsigned live = 0;  // bit r: this wave's block of round r may hold a gaussian that reaches this rank's rows (block-level culling)
+    const int64_t i0 = base + (int64_t)SHARD_PER * threadIdx.x;
+    const bool blk_live = i0 < sc.n && !(blk_dead != nullptr && blk_dead[i0 >> 6]);
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(sc.means) | reinterpret_cast<uintptr_t>(sc.log_scales)) & 15u) == 0;
+    if (blk_live && vec_ok && i0 + SHARD_PER <= sc.n) {
+        const float4 *m4 = reinterpret_cast<const float4 *>(sc.means + 3 * i0), *s4 = reinterpret_cast<const float4 *>(sc.log_scales + 3 * i0);
+        const float4 ma = m4[0], mb = m4[1], mc = m4[2], sa = s4[0], sb = s4[1], sc4 = s4[2];
+        p[0][0] = ma.x; p[0][1] = ma.y; p[0][2] = ma.z; p[1][0] = ma.w; p[1][1] = mb.x; p[1][2] = mb.y;
+        p[2][0] = mb.z; p[2][1] = mb.w; p[2][2] = mc.x; p[3][0] = mc.y; p[3][1] = mc.z; p[3][2] = mc.w;
+        ls[0] = fmaxf(sa.x, fmaxf(sa.y, sa.z)); ls[1] = fmaxf(sa.w, fmaxf(sb.x, sb.y));
+        ls[2] = fmaxf(sb.z, fmaxf(sb.w, sc4.x)); ls[3] = fmaxf(sc4.y, fmaxf(sc4.z, sc4.w));
+    } else {
 #pragma unroll
-    for (int r = 0; r < SHARD_PER; ++r) {
-        const int64_t i = base + r * 256 + threadIdx.x;
-        const bool in = i < sc.n && !(blk_dead != nullptr && blk_dead[i >> 6]);
-        live |= in ? 1u << r : 0u;
+        for (int r = 0; r < SHARD_PER; ++r) {
+            const int64_t i = i0 + r;
+            const bool in = blk_live && i < sc.n;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) p[r][j] = in ? sc.means[3 * i + j] : 0.0f;
-        ls[r] = in ? fmaxf(sc.log_scales[3 * i], fmaxf(sc.log_scales[3 * i + 1], sc.log_scales[3 * i + 2])) : 0.0f;
+            for (int j = 0; j < 3; ++j) p[r][j] = in ? sc.means[3 * i + j] : 0.0f;
+            ls[r] = in ? fmaxf(sc.log_scales[3 * i], fmaxf(sc.log_scales[3 * i + 1], sc.log_scales[3 * i + 2])) : 0.0f;
+        }
     }
-    __syncthreads();
 
     // ---- phase 1: the bound ----
+    uint32_t cand = 0;  // bit r: gaussian i0 + r may reach one of this rank's tile rows
 #pragma unroll
     for (int r = 0; r < SHARD_PER; ++r) {
-        const int64_t i = base + r * 256 + threadIdx.x;
         // the same expressions as geometry_view (this file is built with -ffp-contract=off)
         float cm[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) cm[j] = ((p[r][0] * V[0 + j] + p[r][1] * V[4 + j]) + p[r][2] * V[8 + j]) + V[12 + j];
-        bool k = ((live >> r) & 1u) != 0 && !(cm[2] < GSR_CULL_Z);
+        bool k = blk_live && i0 + r < sc.n && !(cm[2] < GSR_CULL_Z);
         const float pt0 = ((p[r][0] * F[0] + p[r][1] * F[4]) + p[r][2] * F[8]) + F[12];
         const float pt1 = ((p[r][0] * F[1] + p[r][1] * F[5]) + p[r][2] * F[9]) + F[13];
         const float pt3 = ((p[r][0] * F[3] + p[r][1] * F[7]) + p[r][2] * F[11]) + F[15];
@@ -620,13 +635,16 @@ __global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, CamB
             // columns: a rect that lies left or right of the frame clamps to zero width (covering_bbox + the pixel clamp)
             if (fabsf(mx) < 1.0e8f && (mx + Rb < 0.0f || mx - Rb - 16.0f > Wf)) k = false;
         }
-        const uint32_t pos = block_append_256(k, s_wave, &s_ncand);
-        if (k) s_cand[pos] = (uint32_t)i;
+        cand |= k ? 1u << r : 0u;
     }
+    uint32_t ncand;
+    uint32_t cpos = block_excl_scan_256((uint32_t)__popc(cand), s_scan, &ncand);
+#pragma unroll
+    for (int r = 0; r < SHARD_PER; ++r)
+        if ((cand >> r) & 1u) s_cand[cpos++] = (uint32_t)(i0 + r);
     __syncthreads();
 
     // ---- phase 2: geometry of the candidates, 256 at a time; the visible ones are appended in order ----
-    const uint32_t ncand = s_ncand;
     const GsrDebugOut none = {};
     for (uint32_t c0 = 0; c0 < ncand; c0 += 256) {
         const uint32_t j = c0 + threadIdx.x;
@@ -671,35 +689,74 @@ __global__ __launch_bounds__(256) void shard_preprocess_kernel(GsrScene sc, CamB
     }  // views
 }
 
-// Workgroup b moves the run of shard_preprocess workgroup b to its place in the compact arrays: position = records of the
-// workgroups before it (the counts are a few KB, L2-resident, summed here four at a time: cheaper than a scan kernel and
-// its boundary) + rank inside.
+// Workgroup b moves the runs of shard_preprocess workgroups [8 b, 8 b + 8) to their place in the compact arrays: position = records
+// of the workgroups before them (the counts are a few KB, L2-resident, summed here four at a time: cheaper than a scan kernel and
+// its boundary) + rank inside.  Eight runs per workgroup (round 5; one until then: every workgroup paid the sum, the scan's two
+// barriers and one short dependent copy — 44 us for four views of a rank of 8, i.e. ~6000 x 4 workgroups of ~130 records).
+constexpr int COMPACT_RUNS = 8;
 __global__ __launch_bounds__(256) void shard_compact_kernel(const uint32_t *__restrict__ run_key, const uint32_t *__restrict__ run_id,
                                                             const uint32_t *__restrict__ run_rect8, const uint32_t *__restrict__ run_cnt,
                                                             uint32_t *__restrict__ key, uint32_t *__restrict__ id, uint32_t *__restrict__ rect8,
-                                                            uint32_t *__restrict__ n_records, int packed_rect, size_t vstride)
+                                                            uint32_t *__restrict__ n_records, int n_runs, int packed_rect, size_t vstride)
 {
     __shared__ uint32_t scratch[8];
     run_key = view_slice(run_key, vstride); run_id = view_slice(run_id, vstride); run_rect8 = view_slice(run_rect8, vstride);
     run_cnt = view_slice(run_cnt, vstride); key = view_slice(key, vstride); id = view_slice(id, vstride); rect8 = view_slice(rect8, vstride);
     n_records = view_slice(n_records, vstride);
-    const int b = (int)blockIdx.x, quads = b >> 2;
+    const int b0 = (int)blockIdx.x * COMPACT_RUNS, quads = b0 >> 2;  // COMPACT_RUNS is a multiple of 4
     uint32_t mine = 0;
     for (int q = threadIdx.x; q < quads; q += 256) {
         const uint4 c = reinterpret_cast<const uint4 *>(run_cnt)[q];
         mine += (c.x + c.y) + (c.z + c.w);
     }
-    if ((int)threadIdx.x < (b & 3)) mine += run_cnt[4 * quads + threadIdx.x];
     uint32_t before;
     block_excl_scan_256(mine, scratch, &before);
-    const uint32_t cnt = run_cnt[b];
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_records = before + cnt;
-    const size_t src = (size_t)b * SHARD_SPAN;
-    for (uint32_t j = threadIdx.x; j < cnt; j += 256) {
-        key[before + j] = run_key[src + j];
-        id[before + j] = run_id[src + j];
-        if (packed_rect) rect8[before + j] = run_rect8[src + j];
+    // the eight runs as ONE list of T records: record j lies in the run whose prefix it has passed (the eight prefixes stay in
+    // registers), so that every thread's loads are independent of one another — four in flight before the first store
+    uint32_t pre[COMPACT_RUNS + 1];
+    pre[0] = 0;
+    if (b0 + COMPACT_RUNS <= n_runs) {
+        const uint4 c0 = reinterpret_cast<const uint4 *>(run_cnt)[quads], c1 = reinterpret_cast<const uint4 *>(run_cnt)[quads + 1];
+        pre[1] = c0.x; pre[2] = pre[1] + c0.y; pre[3] = pre[2] + c0.z; pre[4] = pre[3] + c0.w;
+        pre[5] = pre[4] + c1.x; pre[6] = pre[5] + c1.y; pre[7] = pre[6] + c1.z; pre[8] = pre[7] + c1.w;
+    } else {
+#pragma unroll
+        for (int r = 0; r < COMPACT_RUNS; ++r) pre[r + 1] = pre[r] + (b0 + r < n_runs ? run_cnt[b0 + r] : 0u);
     }
+    const uint32_t T = pre[COMPACT_RUNS];
+    const size_t src0 = (size_t)b0 * SHARD_SPAN;
+    for (uint32_t j0 = threadIdx.x; j0 < T; j0 += 4 * 256) {
+        uint32_t k[4], d[4], q[4];
+        size_t src[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t j = j0 + u * 256;
+            uint32_t r = 0;
+#pragma unroll
+            for (int t = 1; t < COMPACT_RUNS; ++t) r += j >= pre[t] ? 1u : 0u;
+            uint32_t first = 0;
+#pragma unroll
+            for (int t = 1; t < COMPACT_RUNS; ++t) first = r == (uint32_t)t ? pre[t] : first;
+            src[u] = src0 + (size_t)r * SHARD_SPAN + (j - first);
+            k[u] = d[u] = q[u] = 0;
+            if (j < T) {
+                k[u] = run_key[src[u]];
+                d[u] = run_id[src[u]];
+                if (packed_rect) q[u] = run_rect8[src[u]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t j = j0 + u * 256;
+            if (j < T) {
+                key[before + j] = k[u];
+                id[before + j] = d[u];
+                if (packed_rect) rect8[before + j] = q[u];
+            }
+        }
+    }
+    before += T;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_records = before;
 }
 
 static Cam make_cam(const GsrCamera &c)
@@ -817,8 +874,8 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera *cams, const GsrOpt
         if (h16) { if (colour) GSR_LAUNCH_SHARD(true, true); else GSR_LAUNCH_SHARD(true, false); }
         else { if (colour) GSR_LAUNCH_SHARD(false, true); else GSR_LAUNCH_SHARD(false, false); }
 #undef GSR_LAUNCH_SHARD
-        hipLaunchKernelGGL(shard_compact_kernel, dim3(sgrid, (unsigned)views), dim3(256), 0, s, ws.key[1], ws.val[1], ws.rect8[1], run_cnt, ws.key[0], ws.val[0],
-                           ws.rect8[0], &ws.ctrl->n_records, packed, ws.view_stride);
+        hipLaunchKernelGGL(shard_compact_kernel, dim3((sgrid + COMPACT_RUNS - 1) / COMPACT_RUNS, (unsigned)views), dim3(256), 0, s, ws.key[1], ws.val[1], ws.rect8[1],
+                           run_cnt, ws.key[0], ws.val[0], ws.rect8[0], &ws.ctrl->n_records, (int)sgrid, packed, ws.view_stride);
     } else if (!dbg) {
         if (views > 1) {
             if (h16) { if (colour) GSR_LAUNCH_VIEWS(true, true); else GSR_LAUNCH_VIEWS(true, false); }
