@@ -676,6 +676,23 @@ def test_three_phase_shard_preprocess_on_its_other_paths(G):
         a, b = R.render(cam, mk(shard_preprocess=1, **so)), R.render(cam, mk(shard_preprocess=2, **so))
         assert torch.equal(a, b) and torch.equal(a, R.render(cam, mk(**so))) and bool(a.any()), (step, r)
         assert torch.equal(R.render(cam, mk(shard_preprocess=2, colour_stage=1, **so)), a)
+    # phase 1 reads a thread's four consecutive gaussians as 16-B pieces when means and log-scales are 16-B aligned, word by word
+    # otherwise (and in the last workgroup of a scene whose size is no multiple of four): the same strips from arrays that start 4 bytes
+    # into their buffers, and from a scene of 79 997 gaussians against the whole frame
+    cut = {k: v[:79_997] for k, v in cols.items()}
+    Rc = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cut, spatial_order=False))
+    assert reassembles(Rc, cam, 8)
+    so = dict(tile_row_begin=3, tile_row_step=8, output_layout=2)
+    aligned = Rc.render(cam, mk(**so)).clone()
+    keep = []
+    for k in ("means", "log_scales"):
+        buf = torch.zeros(Rc.scene.t[k].numel() + 1, dtype=torch.float32, device="cuda")
+        buf[1:] = Rc.scene.t[k].reshape(-1)
+        keep.append(buf)
+        Rc.scene.t[k] = buf[1:].view(-1, 3)
+        assert Rc.scene.t[k].data_ptr() % 16 == 4 and Rc.scene.t[k].is_contiguous()
+    assert torch.equal(Rc.render(cam, mk(**so)), aligned) and bool(aligned.any())
+    assert torch.equal(G.renderer.Rasterizer(Rc.scene, views=2).render_batch([cam, cam], mk(**so))[1], aligned)   # two views per launch sequence
 
 
 def test_full_hd_one_million(G):
