@@ -542,8 +542,10 @@ __device__ __forceinline__ uint32_t block_append_256(bool flag, uint32_t *s_wave
     return pos;
 }
 
-// Several views per launch (gsr_render_batch): the workgroup takes its span through one camera after the other — what the first view
-// read from HBM the others find in L2 — writing view v's records and runs into slice v of the workspace.
+// Several views per launch (gsr_render_batch): blockIdx.y is the view, its records and runs go to slice v of the workspace — four views
+// are four times the workgroups, each with ONE three-phase chain (a quarter of them walking four chains one after the other measured
+// 301 against 288 us; phase 1's 24 B per gaussian come from L2 / the infinity cache for three of the four).
+// amdgpu_waves_per_eu: left alone the compiler keeps 106 SGPRs, and a SIMD's 800 hold seven such waves — the eighth costs 25 scalar spills.
 template <bool SH16, bool COLOUR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void shard_preprocess_kernel(GsrScene sc, CamBatch cams, int views, size_t vstride, int compat, int no_cull, int row_begin, int row_step,
                                                                GaussRec *__restrict__ rec0, ushort4 *__restrict__ rect0,
@@ -560,15 +562,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     uint32_t *const s_id = s_cand;
     __shared__ float s_l2op[SHARD_SPAN];
     __shared__ uint32_t s_wave[4], s_scan[8], s_nvis;
-    // one view per workgroup (blockIdx.y): four views are four times the workgroups, each with ONE three-phase chain, instead of a
-    // quarter of them walking four chains one after the other (phase 1's 24 B per gaussian come from L2 for three of the four)
-    const int v_first = (int)blockIdx.y, v_last = v_first + 1;
-    if (blockIdx.x == 0) frame_reset<256>(slice_of(ctrl_words0, v_first, vstride), ctrl_reset_words, sc, cams.cam[v_first]);  // as in preprocess_kernel
+    const int v = (int)blockIdx.y;
+    if (blockIdx.x == 0) frame_reset<256>(slice_of(ctrl_words0, v, vstride), ctrl_reset_words, sc, cams.cam[v]);  // as in preprocess_kernel
     const int64_t base = (int64_t)blockIdx.x * SHARD_SPAN;
     const int tiles_y = (cams.cam[0].H + GSR_TILE - 1) / GSR_TILE;
 
-#pragma unroll 1
-    for (int v = v_first; v < v_last; ++v) {
     const Cam &cam = cams.cam[v];
     GaussRec *__restrict__ rec = slice_of(rec0, v, vstride);
     ushort4 *__restrict__ rect = slice_of(rect0, v, vstride);
@@ -576,8 +574,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     uint32_t *__restrict__ run_rect8 = slice_of(run_rect80, v, vstride), *__restrict__ run_cnt = slice_of(run_cnt0, v, vstride);
     const float *V = cam.V, *F = cam.F;
     const float Wf = (float)cam.W, Hf = (float)cam.H;
-    __syncthreads();  // the previous view's lists have been consumed
-    if (threadIdx.x == 0) s_nvis = 0;
+    if (threadIdx.x == 0) s_nvis = 0;  // (read after the barriers of phase 1's scan)
     // what phase 1 reads: a thread takes FOUR CONSECUTIVE gaussians, ids base + 4 t + r — 48 contiguous bytes of means and of
     // log-scales, three 16-B loads each when the arrays are 16-B aligned (a wave: 3 KB in a row) — so that ONE workgroup scan of the
     // threads' candidate counts puts the list in id order (round 5; before: ids base + 256 r + t, four stable appends of two barriers
@@ -686,7 +683,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         run_id[base + j] = (uint32_t)i;
         if (packed_rect) run_rect8[base + j] = s_rect8[j];
     }
-    }  // views
 }
 
 // Workgroup b moves the runs of shard_preprocess workgroups [8 b, 8 b + 8) to their place in the compact arrays: position = records
