@@ -100,7 +100,7 @@ typedef struct GsrOptions {
                                  exact — identical bits to blending every gaussian like the reference (Q5); see
                                  saturation_rule for what "exact" stops on.  >0 is a bounded approximation (INRIA
                                  uses 1e-4). */
-    int32_t tile_row_begin;   /* multi-GPU sharding: this call bins+blends tile rows begin, begin+step, ... */
+    int32_t tile_row_begin;   /* multi-GPU sharding: this call bins+blends tile rows begin, begin+step, ... (blocks of rows: tile_row_block) */
     int32_t tile_row_step;    /* default 0 / 1 = all rows */
     int32_t output_layout;    /* 0 (default): image [H,W,3] (= screen.transpose(1,0), rasterize.py:471);
                                  1: reference `screen` layout [W,H,3] (rasterize.py:437);
@@ -166,6 +166,12 @@ typedef struct GsrOptions {
     int32_t batch_views;      /* gsr_render_batch / gsr_render_batch_slots: at most this many views per launch sequence; 0 (default) = as many
                                  as the workspace holds slices for, up to GSR_MAX_BATCH_VIEWS.  1 = one view at a time (rounds 1-4).  Same
                                  frames whatever it says. */
+    int32_t tile_row_block;   /* multi-GPU sharding: how many consecutive tile rows form one unit of the interleave.  0 / 1 (default): single
+                                 rows — this call owns tile rows begin, begin + step, ...  2: PAIRS of rows, i.e. the two tile rows of one
+                                 32x32 binning cell — block b = rows 2b, 2b + 1 is owned when b % step == begin.  A rank then bins and sorts
+                                 only the cells it owns (with single rows and an even step every cell row is shared by two ranks, and each
+                                 of them emits and sorts all its pairs); the strip (output_layout = 2) holds the owned rows in ascending
+                                 order either way.  Same pixels; only the partition differs. */
 } GsrOptions;
 
 /* Counters of one frame (device -> host with gsr_read_stats). */

@@ -31,7 +31,7 @@ def test_struct_sizes_match_header():
 
     assert C.sizeof(_lib.GsrScene) == 64 and _lib.GsrScene.block_bounds.offset == 56
     assert C.sizeof(_lib.GsrCamera) == 4 * (16 + 16 + 3 + 6) + 8
-    assert C.sizeof(_lib.GsrOptions) == 80 and _lib.GsrOptions.batch_views.offset == 76 and _lib.GsrOptions.keep_flags.offset == 44 and _lib.GsrOptions.accum_dtype.offset == 40
+    assert C.sizeof(_lib.GsrOptions) == 84 and _lib.GsrOptions.tile_row_block.offset == 80 and _lib.GsrOptions.batch_views.offset == 76 and _lib.GsrOptions.keep_flags.offset == 44 and _lib.GsrOptions.accum_dtype.offset == 40
     assert _lib.GsrOptions.saturation_rule.offset == 48 and _lib.GsrOptions.sh_dense_min.offset == 72 and _lib.GsrOptions.colour_stage.offset == 68 and _lib.GsrOptions.no_order_hint.offset == 64
     assert C.sizeof(_lib.GsrStats) == 48 and _lib.GsrStats.colour_evals.offset == 40 and _lib.GsrStats.wave_entries.offset == 24 and _lib.GsrStats.fetched_entries.offset == 32
     assert C.sizeof(_lib.GsrDebugOut) == 72

@@ -30,7 +30,7 @@ def _worker(rank, world, port, H, W, q):
 
     g = torch.Generator().manual_seed(1234)
     frame = torch.rand((H, W, 3), generator=g)                   # same "rendered frame" on every rank
-    plan = gdist.TileRowPlan(H, W, world)
+    plan = gdist.TileRowPlan(H, W, world, 1 + (H // 16) % 2)    # single rows or pairs of rows, by the frame
     fg = gdist.FrameGather(plan, rank, "cpu")
     own = fg.own_view()
     assert tuple(own.shape) == plan.strip_shape(rank)
@@ -63,7 +63,7 @@ def _pipeline_worker(rank, world, port, H, W, q):
 
     g = torch.Generator().manual_seed(99)
     truth = [torch.rand((H, W, 3), generator=g) for _ in range(14)]
-    plan = gdist.TileRowPlan(H, W, world)
+    plan = gdist.TileRowPlan(H, W, world, 1 + (H // 16) % 2)    # single rows or pairs of rows, by the frame
 
     def render(slot, frame_index, strip):
         strip.copy_(plan.split(truth[frame_index], rank)[: strip.shape[0]])
@@ -148,9 +148,10 @@ def test_plan_covers_every_tile_row_once():
 
     for H in (16, 17, 93, 1080, 2160):
         for world in (1, 2, 3, 4, 8):
-            plan = gdist.TileRowPlan(H, 64, world)
-            rows = sorted(r for rs in plan.rows for r in rs)
-            assert rows == list(range((H + 15) // 16))
-            assert max(len(r) for r in plan.rows) - min(len(r) for r in plan.rows) <= 1
-            frame = torch.arange(H * 64 * 3, dtype=torch.float32).view(H, 64, 3)
-            assert torch.equal(plan.assemble([plan.split(frame, r) for r in range(world)]), frame)
+            for block in (1, 2):
+                plan = gdist.TileRowPlan(H, 64, world, block)
+                rows = sorted(r for rs in plan.rows for r in rs)
+                assert rows == list(range((H + 15) // 16))
+                assert max(len(r) for r in plan.rows) - min(len(r) for r in plan.rows) <= block
+                frame = torch.arange(H * 64 * 3, dtype=torch.float32).view(H, 64, 3)
+                assert torch.equal(plan.assemble([plan.split(frame, r) for r in range(world)]), frame)

@@ -609,9 +609,10 @@ def test_frames_are_bitwise_reproducible(G):
         assert torch.equal(R.render(cam), a)
 
 
-@pytest.mark.parametrize("step", [2, 3, 8])
-def test_tile_row_shards_reassemble_bit_exactly(G, step):
-    """Multi-GPU sharding: interleaved tile rows rendered separately == the full frame."""
+@pytest.mark.parametrize("step,block", [(2, 1), (3, 1), (8, 1), (2, 2), (3, 2), (4, 2), (8, 2)])
+def test_tile_row_shards_reassemble_bit_exactly(G, step, block):
+    """Multi-GPU sharding: interleaved tile rows — single rows, or pairs of rows = whole 32x32 cell rows
+    (GsrOptions.tile_row_block) — rendered separately == the full frame."""
     cols, cam, _ = _medium(G, n=100_000, W=640, H=360)
     R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
     full = R.render(cam)
@@ -621,10 +622,12 @@ def test_tile_row_shards_reassemble_bit_exactly(G, step):
     full_visible = R.last_stats["n_visible"]
     pairs = 0
     for r in range(step):
-        strip = R.render(cam, G.renderer.make_options(tile_row_begin=r, tile_row_step=step, output_layout=2))
+        strip = R.render(cam, G.renderer.make_options(tile_row_begin=r, tile_row_step=step, output_layout=2, tile_row_block=block))
         pairs += R.last_stats["n_pairs"]
         assert 0 < R.last_stats["n_visible"] < full_visible       # a shard only preprocesses/sorts what touches its rows
-        for k, ty in enumerate(range(r, tiles_y, step)):
+        rows = G.renderer.shard_row_list(cam.height, r, step, block)
+        assert rows == [t for t in range(tiles_y) if (t // block) % step == r] and strip.shape[0] == 16 * len(rows)
+        for k, ty in enumerate(rows):
             h = min(16, cam.height - ty * 16)
             out[ty * 16: ty * 16 + h] = strip[k * 16: k * 16 + h]
     assert torch.equal(out, full)
@@ -640,19 +643,19 @@ def test_three_phase_shard_preprocess_on_its_other_paths(G):
     (a debug call on a shard still fills every gaussian's intermediates, then renders the shard correctly)."""
     mk = G.renderer.make_options
 
-    def reassembles(R, cam, step):
+    def reassembles(R, cam, step, block=1):
         full = R.render(cam)
-        tiles_y = (cam.height + 15) // 16
         out = torch.zeros_like(full)
         for r in range(step):
-            strip = R.render(cam, mk(tile_row_begin=r, tile_row_step=step, output_layout=2))
-            for k, ty in enumerate(range(r, tiles_y, step)):
+            strip = R.render(cam, mk(tile_row_begin=r, tile_row_step=step, output_layout=2, tile_row_block=block))
+            for k, ty in enumerate(G.renderer.shard_row_list(cam.height, r, step, block)):
                 h = min(16, cam.height - ty * 16)
                 out[ty * 16: ty * 16 + h] = strip[k * 16: k * 16 + h]
         return torch.equal(out, full) and bool(full.any())
 
     cols, cam, _ = _medium(G, n=80_000, W=640, H=360)
     assert reassembles(G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols, sh_half=True)), cam, 5)
+    assert reassembles(G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols, sh_half=True)), cam, 5, block=2)
     # wide frame: 263 tile columns x 13 tile rows
     W, H = 4200, 200
     wcols = G.synthetic.mip360_like(60_000, 12)
@@ -662,6 +665,7 @@ def test_three_phase_shard_preprocess_on_its_other_paths(G):
     fx = G.synthetic.pinhole_focal(W, 100.0)
     wcam = G.renderer.make_camera(p.qvec, p.tvec, 2 * fx, 2 * fx, 2 * W, 2 * H, W, H)
     assert reassembles(G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(wcols)), wcam, 6)
+    assert reassembles(G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(wcols)), wcam, 6, block=2)   # per-tile pairs, rows in pairs
     # debug outputs on a shard: every gaussian's intermediates, identical to the whole-frame call's
     R = G.renderer.Rasterizer(G.renderer.GaussianScene.from_columns(cols))
     o8 = mk(tile_row_begin=2, tile_row_step=8, output_layout=2)

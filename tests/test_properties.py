@@ -9,13 +9,18 @@ from conftest import golden_columns, load_golden
 
 
 @settings(max_examples=40, deadline=None)
-@given(st.integers(1, 400), st.integers(1, 300), st.integers(1, 9))
-def test_tile_row_plan_partitions_any_frame(H, W, world):
-    from gsr_amd import dist as gdist
+@given(st.integers(1, 400), st.integers(1, 300), st.integers(1, 9), st.integers(1, 2))
+def test_tile_row_plan_partitions_any_frame(H, W, world, block):
+    from gsr_amd import dist as gdist, renderer
 
-    plan = gdist.TileRowPlan(H, W, world)
+    plan = gdist.TileRowPlan(H, W, world, block)
     rows = sorted(r for rs in plan.rows for r in rs)
     assert rows == list(range((H + 15) // 16))
+    for r in range(world):  # the plan's rows are what libgsr's options describe (renderer.shard_row_list restates RowShard::row_at)
+        so = plan.shard_options(r)
+        assert plan.rows[r] == renderer.shard_row_list(H, so["tile_row_begin"], so["tile_row_step"], so["tile_row_block"])
+        if block == 2:
+            assert all(t ^ 1 in plan.rows[r] or t ^ 1 >= plan.tiles_y for t in plan.rows[r])  # whole cell rows
     frame = torch.arange(H * W * 3, dtype=torch.float32).view(H, W, 3)
     strips = [plan.split(frame, r) for r in range(world)]
     assert all(tuple(s.shape) == plan.padded_shape() for s in strips)

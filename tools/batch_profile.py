@@ -23,7 +23,7 @@ del cols
 kw, shape = {}, (H, W, 3)
 if os.environ.get("GSR_SHARD"):
     G, r = (int(x) for x in os.environ["GSR_SHARD"].split())
-    plan = gdist.TileRowPlan(H, W, G)
+    plan = gdist.TileRowPlan(H, W, G, int(os.environ.get("GSR_BLOCK", "2")))
     kw, shape = plan.shard_options(r), plan.strip_shape(r)
 R = renderer.Rasterizer(scene, views=K)
 o0 = renderer.make_options(**kw)

@@ -29,7 +29,7 @@ kw = {}
 shape = (H, W, 3)
 if shard:
     G, r = (int(x) for x in shard.split())
-    plan = gdist.TileRowPlan(H, W, G)
+    plan = gdist.TileRowPlan(H, W, G, int(os.environ.get("GSR_BLOCK", "2")))
     kw = plan.shard_options(r)
     shape = plan.strip_shape(r)
 opts0 = renderer.make_options(**kw)

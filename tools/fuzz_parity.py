@@ -120,14 +120,15 @@ def main():
             assert torch.equal(R.render(cam, mk(saturation_rule=1, early_out_T=-1.0)), img), "early-out differs from blending everything"
             assert torch.equal(R.render(cam, mk(output_bf16=True)), img.to(torch.bfloat16)), "bf16 store"
             step = int(rng.choice([2, 3, 5, 8]))
+            block = int(rng.choice([1, 2]))  # single tile rows, or pairs of rows = whole 32x32 cell rows (GsrOptions.tile_row_block)
             tiles_y = (H + 15) // 16
             full = torch.zeros((tiles_y * 16, W, 3), device=img.device)
             for r in range(step):
-                strip = R.render(cam, mk(tile_row_begin=r, tile_row_step=step, output_layout=2))
-                rows = list(range(r, tiles_y, step))
+                strip = R.render(cam, mk(tile_row_begin=r, tile_row_step=step, output_layout=2, tile_row_block=block))
+                rows = renderer.shard_row_list(H, r, step, block)
                 if rows:
-                    full.view(tiles_y, 16, W, 3)[r::step] = strip.view(len(rows), 16, W, 3)
-            assert torch.equal(full[:H], img), f"shards (step {step}) differ"
+                    full.view(tiles_y, 16, W, 3)[torch.as_tensor(rows, device=img.device)] = strip.view(len(rows), 16, W, 3)
+            assert torch.equal(full[:H], img), f"shards (step {step}, rows in blocks of {block}) differ"
             # -- the other modes, each against an exact property or the oracle ----------------------------------
             assert torch.equal(R.render(cam, mk(output_layout=1)), img.transpose(0, 1)), "layout 1 is not the transpose"
             nc = R.render(cam, mk(reference_compat=False))
@@ -145,7 +146,7 @@ def main():
             want = torch.stack([img if v is cam else img2 for v in views])
             RK = renderer.Rasterizer(scene, max_pairs=int(rng.choice([0, 1000])) or None, views=K)
             assert torch.equal(RK.render_batch(views), want), f"{K} views per launch sequence differ from single views"
-            so = mk(tile_row_begin=int(rng.integers(0, step)), tile_row_step=step, output_layout=2)
+            so = mk(tile_row_begin=int(rng.integers(0, step)), tile_row_step=step, output_layout=2, tile_row_block=block)
             assert torch.equal(RK.render_batch(views, so), torch.stack([R.render(v, so) for v in views])), f"{K} views per launch sequence, shard"
             # block-level culling (GsrScene.block_bounds): the same bits with the bounds, and no skipped block holds a gaussian the
             # reference would draw (its skip guard, rasterize.py:441, on the reference-parity intermediates)

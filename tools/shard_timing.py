@@ -43,7 +43,7 @@ def timed(fif, opts, outs, frames=24, views=1):
 
 
 for G in (1, 2, 4, 8) if only is None else (only[0],):
-    plan = gdist.TileRowPlan(H, W, G)
+    plan = gdist.TileRowPlan(H, W, G, int(os.environ.get("GSR_BLOCK", "2")))
     one, many, vis, pairs = [], [], [], []
     for r in range(G) if only is None else (only[1],):
         impl = int(os.environ.get("GSR_BLEND_IMPL", "0"))  # A/B of blend kernels

@@ -93,6 +93,7 @@ class GsrOptions(C.Structure):
         ("colour_stage", C.c_int32),
         ("sh_dense_min", C.c_int32),
         ("batch_views", C.c_int32),
+        ("tile_row_block", C.c_int32),
     ]
 
 

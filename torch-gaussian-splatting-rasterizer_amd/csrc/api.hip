@@ -84,6 +84,7 @@ static int check_frame(int64_t n, const GsrCamera *cam, const GsrOptions *opts, 
     if (opts->tile_row_step < 0 || opts->tile_row_begin < 0 || opts->tile_row_begin >= std::max(opts->tile_row_step, 1)) {
         set_error("bad tile-row shard %d/%d", opts->tile_row_begin, opts->tile_row_step); return GSR_ERR_BAD_ARG;
     }
+    if (opts->tile_row_block < 0 || opts->tile_row_block > 2) { set_error("bad tile_row_block %d (0 / 1: single rows, 2: pairs)", opts->tile_row_block); return GSR_ERR_BAD_ARG; }
     if (opts->draw_limit < 0) { set_error("bad draw_limit %d", opts->draw_limit); return GSR_ERR_BAD_ARG; }
     if (opts->output_dtype != 0 && opts->output_dtype != 1) { set_error("bad output_dtype %d", opts->output_dtype); return GSR_ERR_BAD_ARG; }
     if (opts->blend_impl < 0 || opts->blend_impl > 1) { set_error("bad blend_impl %d", opts->blend_impl); return GSR_ERR_BAD_ARG; }
@@ -338,8 +339,8 @@ static int check_batch(const GsrScene *scene, const GsrCamera *cams, int32_t n_c
     // what one view writes: the frame, or (output_layout = 2) the strip of its shard's tile rows
     int64_t rows_px = cams[0].height;
     if (n_cams > 0 && opts->output_layout == 2) {
-        const int step = std::max(opts->tile_row_step, 1), tiles_y = (cams[0].height + GSR_TILE - 1) / GSR_TILE;
-        rows_px = opts->tile_row_begin < tiles_y ? (int64_t)((tiles_y - opts->tile_row_begin + step - 1) / step) * GSR_TILE : 0;
+        const int tiles_y = (cams[0].height + GSR_TILE - 1) / GSR_TILE;
+        rows_px = (int64_t)row_shard_of(*opts).rows_before(tiles_y) * GSR_TILE;
     }
     if (n_cams > 0 && frame_stride < (int64_t)cams[0].width * rows_px * 3) { set_error("frame_stride smaller than a frame"); return GSR_ERR_BAD_ARG; }
     return GSR_OK;

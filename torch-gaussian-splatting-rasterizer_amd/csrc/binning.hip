@@ -41,28 +41,13 @@ namespace gsr {
 #endif
 constexpr uint32_t CULL_MIN_TILES = GSR_CULL_MIN_TILES;
 
-struct Shard {
-    int begin, step;
-};
-
-// rows ty in [ty0, ty1) with (ty - begin) % step == 0:  first such row and how many
-__device__ __forceinline__ void shard_rows(int ty0, int ty1, Shard sh, int *first, int *rows)
+// The rank's rows of a rect: strip index (RowShard::rows_before) of the first of its rows in [ty0, ty1) and how many; row k of them is
+// sh.row_at(first + k).  (A RowShard at tile level, or — coarse binning — at the level of the 32x32 cells.)
+__device__ __forceinline__ uint32_t tiles_of(ushort4 rc, RowShard sh, int *first_index)
 {
-    int f = ty0;
-    if (sh.step > 1) {
-        int r = (ty0 - sh.begin) % sh.step;
-        if (r < 0) r += sh.step;
-        f = r == 0 ? ty0 : ty0 + (sh.step - r);
-    }
-    *first = f;
-    *rows = f < ty1 ? (ty1 - f + sh.step - 1) / sh.step : 0;
-}
-
-__device__ __forceinline__ uint32_t tiles_of(ushort4 rc, Shard sh, int *first_row)
-{
-    int rows;
-    shard_rows(rc.y, rc.w, sh, first_row, &rows);
-    return (uint32_t)rows * (uint32_t)(rc.z - rc.x);
+    const int k0 = sh.rows_before(rc.y), k1 = rc.w > rc.y ? sh.rows_before(rc.w) : k0;
+    *first_index = k0;
+    return (uint32_t)(k1 - k0) * (uint32_t)(rc.z - rc.x);
 }
 
 __device__ __forceinline__ ushort4 unpack_rect8(uint32_t r)
@@ -107,7 +92,7 @@ static_assert(EMIT_THREADS == 256, "a lane of the count kernel takes EMIT_THREAD
 template <bool PACKED, bool COARSE>
 __global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t *__restrict__ id_a, const uint32_t *__restrict__ id_b,
                                                                   const uint32_t *__restrict__ r8_a, const uint32_t *__restrict__ r8_b,
-                                                                  const FrameCtrl *ctrl, const ushort4 *__restrict__ rect, Shard sh,
+                                                                  const FrameCtrl *ctrl, const ushort4 *__restrict__ rect, RowShard sh,
                                                                   uint32_t *__restrict__ blk_sum, uint2 *__restrict__ ranges,
                                                                   int n_tiles, uint32_t draw_limit, uint2 *__restrict__ cranges, int n_ctiles,
                                                                   FrameCtrl *ctrl_w, uint32_t ent_off, int nblk_n, size_t vstride)
@@ -230,11 +215,11 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(uint32_t *__restrict__ 
 template <bool PACKED, bool COARSE, typename KeyT>  // KeyT: uint16_t when the keys fit (pair_keys_16bit), else uint32_t
 __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t *__restrict__ id_a, const uint32_t *__restrict__ id_b,
                                                                  const uint32_t *__restrict__ r8_a, const uint32_t *__restrict__ r8_b,
-                                                                 const FrameCtrl *ctrl, const ushort4 *__restrict__ rect, Shard sh,
+                                                                 const FrameCtrl *ctrl, const ushort4 *__restrict__ rect, RowShard sh,
                                                                  int bits_x, int tiles_y, const GaussRec *__restrict__ rec,
                                                                  const uint32_t *blk_off, uint32_t max_pairs,
                                                                  KeyT *__restrict__ pkey, uint32_t *__restrict__ pval,
-                                                                 uint32_t draw_limit, Shard tsh, uint32_t *blk_entries /* = blk_off: no __restrict__ on either */,
+                                                                 uint32_t draw_limit, RowShard tsh, uint32_t *blk_entries /* = blk_off: no __restrict__ on either */,
                                                                  size_t vstride)
 {
     id_a = view_slice(id_a, vstride); id_b = view_slice(id_b, vstride); r8_a = view_slice(r8_a, vstride); r8_b = view_slice(r8_b, vstride);
@@ -244,7 +229,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
     __shared__ uint32_t s_off[EMIT_THREADS];   // exclusive pair offset of each gaussian inside the workgroup
     __shared__ uint32_t s_id[EMIT_THREADS];
     __shared__ uint32_t s_geo[EMIT_THREADS];   // x0 | width << 16
-    __shared__ int s_first[EMIT_THREADS];      // first tile row of the shard, or -1 - first when the rect is culled per tile
+    __shared__ int s_first[EMIT_THREADS];      // strip index of the rect's first row of the shard, or -1 - that when the rect is culled per tile
     __shared__ float4 s_q0[EMIT_THREADS];
     __shared__ float4 s_q1[EMIT_THREADS];
     __shared__ uint32_t s_fine[COARSE ? EMIT_THREADS : 1];  // coarse: the gaussian's packed TILE rect
@@ -292,7 +277,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
         row_col(k, geo >> 16, &row, &col);
         const int fr = s_first[lo];
         const bool tested = fr < 0;
-        const int ty = (tested ? -1 - fr : fr) + (int)row * sh.step, tx = (int)(geo & 0xFFFFu) + (int)col;
+        const int ty = sh.row_at((tested ? -1 - fr : fr) + (int)row), tx = (int)(geo & 0xFFFFu) + (int)col;
         const unsigned long long o = base + j;
         if (o < (unsigned long long)max_pairs) {
             if (COARSE) {
@@ -306,7 +291,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int fx = 2 * tx + (q & 1), fy = 2 * ty + (q >> 1);
-                    const bool mine = tsh.step <= 1 || (fy >= tsh.begin && (fy - tsh.begin) % tsh.step == 0);
+                    const bool mine = tsh.owns(fy);
                     mask |= (fx >= x0 && fx <= x1 && fy >= y0 && fy <= y1 && mine) ? 1u << q : 0u;
                 }
                 const bool hit = mask != 0u && (!tested || footprint_hits_rect(s_q0[lo], s_q1[lo], (float)(tx * 32), (float)(tx * 32 + 31),
@@ -417,11 +402,13 @@ int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s)
     const unsigned nv = (unsigned)ws.views;  // gridDim.y: one workspace slice per view
     const size_t vs = ws.view_stride;
     const bool packed_rect = rect_fits_8bit(ws);
-    const Shard sh = {opts.tile_row_begin, opts.tile_row_step < 1 ? 1 : opts.tile_row_step};
-    // cells of a shard: with an even row step the rank's tile rows begin + k step fall into the cell rows (begin >> 1) + k (step >> 1),
-    // each holding exactly one of them; with an odd step (or none) every cell row can hold one.  The expansion keeps only this
-    // rank's tiles either way.
-    const Shard csh = (sh.step > 1 && sh.step % 2 == 0) ? Shard{sh.begin >> 1, sh.step >> 1} : Shard{0, 1};
+    const RowShard sh = row_shard_of(opts);
+    // cells of a shard: pairs of rows (tile_row_block = 2) ARE cell rows — the rank owns cell rows begin + k step whole; with single rows
+    // and an even step the rank's tile rows begin + k step fall into the cell rows (begin >> 1) + k (step >> 1), each holding exactly one
+    // of them; with an odd step (or none) every cell row can hold one.  The expansion keeps only this rank's tiles either way.
+    const RowShard csh = sh.step <= 1 ? RowShard{0, 1, 0}
+                       : sh.bshift == 1 ? RowShard{sh.begin, sh.step, 0}
+                       : sh.step % 2 == 0 ? RowShard{sh.begin >> 1, sh.step >> 1, 0} : RowShard{0, 1, 0};
     const TileKeying tk = tile_keying(ws, opts);
     const int n_ctiles = ws.ctiles_x * ws.ctiles_y;
     const uint32_t cap = (uint32_t)ws.max_pairs;

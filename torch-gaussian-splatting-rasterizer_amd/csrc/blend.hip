@@ -917,7 +917,7 @@ __device__ __forceinline__ void stat_colour_evals(uint32_t mine, uint32_t *s_col
 // Which tile lands where inside a bucket is not deterministic; nothing observable depends on it.
 // Also leaves the longest list length in ctrl (stats).
 __global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict__ ranges, FrameCtrl *ctrl, int tiles_x,
-                                                         int row_begin, int row_step, int rows, int slots_per_group,
+                                                         RowShard rs, int rows, int slots_per_group,
                                                          int *__restrict__ order, uint32_t stats_off, const uint2 *__restrict__ cranges,
                                                          int ctiles_x, const uint32_t *__restrict__ tile_work, size_t vstride)
 {
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const uint2 *__restrict
     bucket_cnt[tid] = 0;
     for (int j = n + tid; j < slots_per_group; j += 256) order[8 * j + g] = -1;
     __syncthreads();
-    auto tile_of = [&](int j) { return (row_begin + (g + 8 * (j / tiles_x)) * row_step) * tiles_x + (j % tiles_x); };
+    auto tile_of = [&](int j) { return rs.row_at(g + 8 * (j / tiles_x)) * tiles_x + (j % tiles_x); };  // the group's rows: strip rows g, g + 8, ...
     // cell lists (cranges != nullptr): the length of the tile's CELL list, an upper bound of what the tile will keep of it
     // The work of a tile is what its blend STAGES before it saturates, which its list length only bounds.  Where the last frame
     // rendered on this workspace left that count for the tile (1 + entries; a fresh workspace holds anything), it is the better
@@ -1073,12 +1073,12 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs args)
         size_t o;
         if (a.layout == 0) o = ((size_t)py * a.W + px) * 3;                                           // image [H,W,3]
         else if (a.layout == 1) o = ((size_t)px * a.H + py) * 3;                                      // screen [W,H,3]
-        else o = ((size_t)(((ty - a.row_begin) / a.row_step) * 16 + (py - ty * 16)) * a.W + px) * 3;  // strip
+        else o = ((size_t)(a.rs.index_of(ty) * 16 + (py - ty * 16)) * a.W + px) * 3;  // strip
         store_rgb(a, o, r, g, b);
         if (a.out_T) {
             const size_t ot = a.layout == 1 ? (size_t)px * a.H + py
                             : a.layout == 0 ? (size_t)py * a.W + px
-                                            : (size_t)(((ty - a.row_begin) / a.row_step) * 16 + (py - ty * 16)) * a.W + px;
+                                            : (size_t)(a.rs.index_of(ty) * 16 + (py - ty * 16)) * a.W + px;
             a.out_T[ot] = drawn ? T : 1.0f;
         }
     }
@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__(256 / QPW, PIPE ? 5 : 8) void blend_walk_kernel(Ble
             const float r = drawn ? Cr : 0.0f, g = drawn ? Cg : 0.0f, b = drawn ? Cb : 0.0f;
             const size_t pix = a.layout == 0 ? (size_t)py * a.W + x                                           // image [H,W,3]
                              : a.layout == 1 ? (size_t)x * a.H + py                                           // screen [W,H,3]
-                                             : (size_t)(((ty - a.row_begin) / a.row_step) * 16 + (py - ty * 16)) * a.W + x;  // strip
+                                             : (size_t)(a.rs.index_of(ty) * 16 + (py - ty * 16)) * a.W + x;  // strip
             store_rgb(a, pix * 3, r, g, b);
             if (a.out_T) a.out_T[pix] = drawn ? T : 1.0f;
         }
@@ -1245,9 +1245,8 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     a.xlim = opts.reference_compat ? cam.width - 1 : cam.width;
     a.ylim = opts.reference_compat ? cam.height - 1 : cam.height;
     a.tiles_x = ws.tiles_x;
-    a.row_step = opts.tile_row_step < 1 ? 1 : opts.tile_row_step;
-    a.row_begin = opts.tile_row_begin;
-    a.rows = a.row_begin < ws.tiles_y ? (ws.tiles_y - a.row_begin + a.row_step - 1) / a.row_step : 0;
+    a.rs = row_shard_of(opts);
+    a.rows = a.rs.rows_before(ws.tiles_y);
     a.layout = opts.output_layout;
     a.out_bf16 = opts.output_dtype == 1;
     a.early_T = opts.early_out_T;
@@ -1258,7 +1257,7 @@ int launch_blend(const GsrCamera &cam, const GsrOptions &opts, const Workspace &
     const int rows_per_xcd = (a.rows + 7) / 8;
     const int slots_per_group = rows_per_xcd * a.tiles_x;
     a.order = ws.tile_order;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(8, nv), dim3(256), 0, s, ws.ranges, ws.ctrl, a.tiles_x, a.row_begin, a.row_step, a.rows,
+    hipLaunchKernelGGL(tile_order_kernel, dim3(8, nv), dim3(256), 0, s, ws.ranges, ws.ctrl, a.tiles_x, a.rs, a.rows,
                        slots_per_group, ws.tile_order,
                        (uint32_t)(reinterpret_cast<const char *>(ws.blend_stats) - reinterpret_cast<const char *>(ws.ctrl)),
                        a.cell_lists ? ws.cranges : nullptr, ws.ctiles_x, opts.no_order_hint ? nullptr : ws.tile_work, ws.view_stride);

@@ -20,7 +20,8 @@ struct BlendArgs {
     int W, H;
     int xlim, ylim;       // pixels x < xlim, y < ylim are drawn (W-1/H-1 in reference_compat: Q1)
     int tiles_x;
-    int row_begin, row_step, rows;  // tile rows of this shard: row_begin + k*row_step, k in [0, rows)
+    RowShard rs;          // tile rows of this shard (gsr_internal.h)
+    int rows;             // how many: strip rows k in [0, rows) <-> tile rows rs.row_at(k)
     int layout;
     int out_bf16;
     float early_T;
@@ -55,7 +56,7 @@ __device__ __forceinline__ BlendArgs blend_args_of_view(const BlendArgs &a)
     b.tile_work = at(a.tile_work, o);
     b.order = at(a.order, o);
     b.W = a.W; b.H = a.H; b.xlim = a.xlim; b.ylim = a.ylim; b.tiles_x = a.tiles_x;
-    b.row_begin = a.row_begin; b.row_step = a.row_step; b.rows = a.rows;
+    b.rs = a.rs; b.rows = a.rows;
     b.layout = a.layout; b.out_bf16 = a.out_bf16; b.early_T = a.early_T; b.sat_scale = a.sat_scale;
     b.col_means = a.col_means; b.col_sh = a.col_sh;
     b.col_cc[0] = a.col_cc[0]; b.col_cc[1] = a.col_cc[1]; b.col_cc[2] = a.col_cc[2];

@@ -172,6 +172,36 @@ TileKeying tile_keying(const Workspace &ws, const GsrOptions &opts);
 inline bool rect_fits_8bit(const Workspace &ws) { return ws.tiles_x <= 256 && ws.tiles_y <= 256; }
 // Can this frame bin per 32x32 cell (binning.hip)?  Needs the packed rect and pair values of 28 id bits + 4 mask bits.
 inline bool coarse_capable(const Workspace &ws) { return rect_fits_8bit(ws) && ws.n <= ((int64_t)1 << 28); }
+// Which tile rows a rank owns (multi-GPU sharding, GsrOptions.tile_row_begin / _step / _block): blocks of 2^bshift consecutive tile
+// rows, block b is the rank's when b % step == begin.  bshift 0: the rows begin, begin + step, ...; bshift 1: pairs of rows = the
+// tile rows of one 32x32 cell row.  The rank's rows in ascending order are its STRIP rows (output_layout = 2): index k <-> row_at(k).
+struct RowShard {
+    int begin, step, bshift;
+    // how many of the rank's rows lie below tile row t (t >= 0) = strip index of its first row >= t
+    __host__ __device__ __forceinline__ int rows_before(int t) const
+    {
+        if (step <= 1) return t;
+        const int b = t >> bshift, q = b / step, r = b - q * step;
+        int k = (q + (begin < r ? 1 : 0)) << bshift;         // whole blocks of the rank below block b
+        if (r == begin) k += t & ((1 << bshift) - 1);        // t lies inside one of its blocks: that block's rows below t
+        return k;
+    }
+    __host__ __device__ __forceinline__ int row_at(int k) const
+    {
+        if (bshift == 0) return k * step + begin;
+        return ((((k >> bshift) * step) + begin) << bshift) | (k & ((1 << bshift) - 1));
+    }
+    __host__ __device__ __forceinline__ bool owns(int t) const { return step <= 1 || (t >> bshift) % step == begin; }
+    // strip index of a row the rank owns
+    __host__ __device__ __forceinline__ int index_of(int t) const { return (((t >> bshift) / step) << bshift) | (t & ((1 << bshift) - 1)); }
+    // any of the rank's rows in [t0, t1)?
+    __host__ __device__ __forceinline__ bool any_in(int t0, int t1) const { return t1 > t0 && (step <= 1 || rows_before(t1) > rows_before(t0)); }
+};
+inline RowShard row_shard_of(const GsrOptions &o)
+{
+    return RowShard{o.tile_row_begin, o.tile_row_step < 1 ? 1 : o.tile_row_step, o.tile_row_block == 2 ? 1 : 0};
+}
+
 // A multi-GPU shard's preprocess (preprocess.hip) hands the depth sort a compact list of (key, id, rect) records of the rank's
 // visible gaussians instead of one key per gaussian.  Progressive frames (draw_limit) rank ALL gaussians the reference
 // draws, so they take the whole-frame path.

@@ -87,7 +87,7 @@ __device__ __forceinline__ bool culled_by(const Cam &cam, const float p[3])
 //     [floor((my - Rb) / 16), floor((my + Rb + 15) / 16)) miss the frame — or miss this rank's tile rows — cannot be drawn.  Rb carries
 //     0.1 % + 1 px + 1e-4 of the coordinates' magnitude more here for this function's own roundings.
 // Anything non-finite compares false and keeps the block.
-__device__ __forceinline__ bool block_dead(const float *__restrict__ bb, const Cam &cam, int row_begin, int row_step)
+__device__ __forceinline__ bool block_dead(const float *__restrict__ bb, const Cam &cam, RowShard rs)
 {
     const float4 b0 = *reinterpret_cast<const float4 *>(bb), b1 = *reinterpret_cast<const float4 *>(bb + 4);
     const float lo[3] = {b0.x, b0.y, b0.z}, hi[3] = {b0.w, b1.x, b1.y};
@@ -133,19 +133,14 @@ __device__ __forceinline__ bool block_dead(const float *__restrict__ bb, const C
     const int tiles_y = (cam.H + GSR_TILE - 1) / GSR_TILE;
     const int row_lo = max((int)floorf((my_lo - Rb) * 0.0625f), 0), row_hi = min((int)floorf((my_hi + Rb + 15.0f) * 0.0625f) - 1, tiles_y - 1);
     if (row_lo > row_hi) return true;                                  // above or below it
-    if (row_step > 1) {                                                // none of this rank's tile rows in between
-        int rr = (row_lo - row_begin) % row_step;
-        if (rr < 0) rr += row_step;
-        if ((rr == 0 ? row_lo : row_lo + (row_step - rr)) > row_hi) return true;
-    }
-    return false;
+    return !rs.any_in(row_lo, row_hi + 1);                             // none of this rank's tile rows in between
 }
 
 // Geometry of gaussian `i` seen from one camera: everything rasterize.py:354-420 computes per gaussian except the colour.  `in` is only
 // read when the gaussian is not culled (or DEBUG): callers may leave it unloaded for a gaussian culled_by() the camera.
 template <bool DEBUG>
-__device__ __forceinline__ GeoOut geometry_view(const float p[3], const GeoIn &in, const Cam &cam, int compat, int no_cull, int row_begin,
-                                                int row_step, int keep_ref_drawn, const GsrDebugOut &dbg, int64_t i)
+__device__ __forceinline__ GeoOut geometry_view(const float p[3], const GeoIn &in, const Cam &cam, int compat, int no_cull, RowShard rs,
+                                                int keep_ref_drawn, const GsrDebugOut &dbg, int64_t i)
 {
     GeoOut g;
     g.visible = g.keep_empty = false;
@@ -252,14 +247,9 @@ __device__ __forceinline__ GeoOut geometry_view(const float p[3], const GeoIn &i
         else {
             tx0 = (int)fx0 >> 4; tx1 = ((int)fx1 >> 4) + 1;
             ty0 = (int)fy0 >> 4; ty1 = ((int)fy1 >> 4) + 1;
-            // multi-GPU shard (tile rows row_begin, row_begin + row_step, ...): a gaussian that touches none of this
-            // rank's rows leaves here, before the 192-B SH read, and never enters this rank's sorts
-            if (row_step > 1) {
-                int r = (ty0 - row_begin) % row_step;
-                if (r < 0) r += row_step;
-                const int first = r == 0 ? ty0 : ty0 + (row_step - r);
-                if (first >= ty1) visible = false;
-            }
+            // multi-GPU shard (RowShard: the rank's tile rows): a gaussian that touches none of this rank's rows leaves here,
+            // before the 192-B SH read, and never enters this rank's sorts
+            if (!rs.any_in(ty0, ty1)) visible = false;
         }
     }
 
@@ -273,7 +263,7 @@ __device__ __forceinline__ GeoOut geometry_view(const float p[3], const GeoIn &i
 
 // One gaussian, one camera: load + view.  A gaussian behind the cull plane leaves after its 12-B mean (no debug outputs wanted).
 template <bool DEBUG>
-__device__ __forceinline__ GeoOut geometry_one(const GsrScene &sc, const Cam &cam, int compat, int no_cull, int row_begin, int row_step,
+__device__ __forceinline__ GeoOut geometry_one(const GsrScene &sc, const Cam &cam, int compat, int no_cull, RowShard rs,
                                                int keep_ref_drawn, const GsrDebugOut &dbg, int64_t i)
 {
     const float p[3] = {sc.means[3 * i], sc.means[3 * i + 1], sc.means[3 * i + 2]};
@@ -283,7 +273,7 @@ __device__ __forceinline__ GeoOut geometry_one(const GsrScene &sc, const Cam &ca
         return g;
     }
     const GeoIn in = geometry_load(sc, i);
-    return geometry_view<DEBUG>(p, in, cam, compat, no_cull, row_begin, row_step, keep_ref_drawn, dbg, i);
+    return geometry_view<DEBUG>(p, in, cam, compat, no_cull, rs, keep_ref_drawn, dbg, i);
 }
 
 // Colour of gaussian `i` seen from the camera: sh_to_rgb, spherical_harmonics.py:27-73 (rasterize.py:368).
@@ -365,7 +355,7 @@ constexpr int PRE_THREADS = GSR_PRE_THREADS;
 // (negative: a colour is clamped to [0, 1], Q7) and the 192-B SH row is not touched here: 44 B read per gaussian instead of up to 236.
 constexpr float COLOUR_PENDING = -1.0f;
 template <bool DEBUG, bool SH16, bool COLOUR>
-__global__ __launch_bounds__(PRE_THREADS, !COLOUR ? 8 : (SH16 && !DEBUG) ? 6 : 4) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, int row_begin, int row_step, int keep_ref_drawn, GaussRec *__restrict__ rec,
+__global__ __launch_bounds__(PRE_THREADS, !COLOUR ? 8 : (SH16 && !DEBUG) ? 6 : 4) void preprocess_kernel(GsrScene sc, Cam cam, int compat, int no_cull, RowShard rs, int keep_ref_drawn, GaussRec *__restrict__ rec,
                                                          ushort4 *__restrict__ rect, uint32_t *__restrict__ rect8, uint32_t *__restrict__ depth_key,
                                                          GsrDebugOut dbg,
                                                          uint32_t *__restrict__ ctrl_words, int ctrl_reset_words, int packed_rect, int sh_dense_min,
@@ -385,7 +375,7 @@ __global__ __launch_bounds__(PRE_THREADS, !COLOUR ? 8 : (SH16 && !DEBUG) ? 6 : 4
         return;
     }
     // (the gaussian id is not written: pass 0 of the depth sort synthesises the identity payload, 8 B per gaussian less traffic)
-    const GeoOut g = geometry_one<DEBUG>(sc, cam, compat, no_cull, row_begin, row_step, keep_ref_drawn, dbg, i);
+    const GeoOut g = geometry_one<DEBUG>(sc, cam, compat, no_cull, rs, keep_ref_drawn, dbg, i);
     float rgb[3] = {COLOUR_PENDING, COLOUR_PENDING, COLOUR_PENDING};
     bool coloured = !COLOUR;
     if constexpr (WAVE_SH) {
@@ -443,7 +433,7 @@ __device__ __forceinline__ T *slice_of(T *p, int v, size_t vstride)
 
 template <bool SH16, bool COLOUR>
 __global__ __launch_bounds__(PRE_THREADS, COLOUR ? 4 : 6) void preprocess_views_kernel(GsrScene sc, CamBatch cams, int views, size_t vstride, int compat, int no_cull,
-                                                                                int row_begin, int row_step, int keep_ref_drawn, GaussRec *__restrict__ rec0,
+                                                                                RowShard rs, int keep_ref_drawn, GaussRec *__restrict__ rec0,
                                                                                 ushort4 *__restrict__ rect0, uint32_t *__restrict__ rect80,
                                                                                 uint32_t *__restrict__ depth_key0, uint32_t *__restrict__ ctrl_words0,
                                                                                 int ctrl_reset_words, int packed_rect, const unsigned char *__restrict__ blk_dead0)
@@ -473,7 +463,7 @@ __global__ __launch_bounds__(PRE_THREADS, COLOUR ? 4 : 6) void preprocess_views_
             continue;
         }
         if (!loaded && !culled_by(cam, p)) { in = geometry_load(sc, i); loaded = true; }
-        const GeoOut g = geometry_view<false>(p, in, cam, compat, no_cull, row_begin, row_step, keep_ref_drawn, none, i);
+        const GeoOut g = geometry_view<false>(p, in, cam, compat, no_cull, rs, keep_ref_drawn, none, i);
         uint32_t *depth_key = slice_of(depth_key0, v, vstride);
         if (!g.visible) {  // as in preprocess_kernel
             if (g.keep_empty) {
@@ -498,7 +488,7 @@ __global__ __launch_bounds__(PRE_THREADS, COLOUR ? 4 : 6) void preprocess_views_
     }
 }
 
-// ---- multi-GPU shard (tile rows row_begin, row_begin + row_step, ...) ---------------------------------------------------
+// ---- multi-GPU shard (the tile rows of a RowShard: begin, begin + step, ... or pairs of rows) ---------------------------------------------------
 // A rank of G keeps ~1/G of the gaussians, but which ones depends on the camera, so every rank has to look at all N.  Run
 // through the kernel above, nearly every wave still holds a few survivors and walks the whole path with most lanes idle
 // (G = 8: 41 % of the lanes pass a cheap bound, 13 % are visible), and pass 0 of the depth sort then scans N keys to drop
@@ -518,7 +508,7 @@ __global__ __launch_bounds__(PRE_THREADS, COLOUR ? 4 : 6) void preprocess_views_
 // of [floor((my - Rb) / 16), floor((my + Rb + 15) / 16)) — the reference rect ends BEFORE tile row tb3 (pixel rows < 16 tb3,
 // rasterize.py:271-272, :415-418) — and of the frame's [0, tiles_y); if no row of this rank lies in there the gaussian cannot
 // reach it, and neither can one whose columns, bounded the same way, miss the frame.
-// Anything non-finite stays a candidate.  (Property-tested against row_step = 1: shards reassemble bit-exactly.)
+// Anything non-finite stays a candidate.  (Property-tested against the whole frame: shards reassemble bit-exactly.)
 constexpr int SHARD_PER = 4, SHARD_SPAN = 256 * SHARD_PER;  // gaussians per thread / per workgroup in phase 1
 
 // Stable append of the flagged threads' items to an LDS list, in thread order.  Returns this thread's position (valid when
@@ -547,7 +537,7 @@ __device__ __forceinline__ uint32_t block_append_256(bool flag, uint32_t *s_wave
 // 301 against 288 us; phase 1's 24 B per gaussian come from L2 / the infinity cache for three of the four).
 // amdgpu_waves_per_eu: left alone the compiler keeps 106 SGPRs, and a SIMD's 800 hold seven such waves — the eighth costs 25 scalar spills.
 template <bool SH16, bool COLOUR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void shard_preprocess_kernel(GsrScene sc, CamBatch cams, int views, size_t vstride, int compat, int no_cull, int row_begin, int row_step,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void shard_preprocess_kernel(GsrScene sc, CamBatch cams, int views, size_t vstride, int compat, int no_cull, RowShard rs,
                                                                GaussRec *__restrict__ rec0, ushort4 *__restrict__ rect0,
                                                                uint32_t *__restrict__ run_key0, uint32_t *__restrict__ run_id0,
                                                                uint32_t *__restrict__ run_rect80, uint32_t *__restrict__ run_cnt0,
@@ -625,10 +615,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const float Rb = 3.0f * sqrtf(1.02f * trb + 0.4f) + 1.5f;
         if (k && Rb < 1.0e8f && fabsf(my) < 1.0e8f) {
             const int lo = max((int)floorf((my - Rb) * 0.0625f), 0), hi = min((int)floorf((my + Rb + 15.0f) * 0.0625f) - 1, tiles_y - 1);
-            int rr = (lo - row_begin) % row_step;
-            if (rr < 0) rr += row_step;
-            const int first = rr == 0 ? lo : lo + (row_step - rr);
-            if (first > hi) k = false;
+            if (!rs.any_in(lo, hi + 1)) k = false;
             // columns: a rect that lies left or right of the frame clamps to zero width (covering_bbox + the pixel clamp)
             if (fabsf(mx) < 1.0e8f && (mx + Rb < 0.0f || mx - Rb - 16.0f > Wf)) k = false;
         }
@@ -650,7 +637,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         int64_t i = 0;
         if (j < ncand) {
             i = (int64_t)s_cand[j];
-            g = geometry_one<false>(sc, cam, compat, no_cull, row_begin, row_step, 0, none, i);
+            g = geometry_one<false>(sc, cam, compat, no_cull, rs, 0, none, i);
         }
         const uint32_t pos = block_append_256(g.visible, s_wave, &s_nvis);
         if (g.visible) {
@@ -788,20 +775,20 @@ static Cam make_cam(const GsrCamera &c)
 // block).  ~100 K threads of a few hundred flops: a few microseconds, against reading 44 B per gaussian of the blocks it rules out.
 // (Round 5 first ran the test inside the preprocess, once per workgroup: 256 lanes each redoing it took the kernel from 128 to
 // 173 us.)  Also gsr_block_visibility (tests and tooling: which blocks does a view skip?).
-__global__ __launch_bounds__(256) void block_flags_kernel(GsrScene sc, CamBatch cams, size_t vstride, int row_begin, int row_step,
+__global__ __launch_bounds__(256) void block_flags_kernel(GsrScene sc, CamBatch cams, size_t vstride, RowShard rs,
                                                           unsigned char *__restrict__ dead0)
 {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t nblk = (sc.n + GSR_BOUNDS_BLOCK - 1) / GSR_BOUNDS_BLOCK;
-    if (b < nblk) view_slice(dead0, vstride)[b] = block_dead(sc.block_bounds + 8 * b, cams.cam[blockIdx.y], row_begin, row_step) ? 1 : 0;
+    if (b < nblk) view_slice(dead0, vstride)[b] = block_dead(sc.block_bounds + 8 * b, cams.cam[blockIdx.y], rs) ? 1 : 0;
 }
 
 static void launch_block_flags(const GsrScene &scene, const CamBatch &kb, int views, size_t vstride, const GsrOptions &opts, unsigned char *dead, hipStream_t s)
 {
     const int64_t nblk = (scene.n + GSR_BOUNDS_BLOCK - 1) / GSR_BOUNDS_BLOCK;
     // progressive frames rank every gaussian the reference draws, whatever rows it touches: no row test then
-    const int row_step = opts.tile_row_step < 1 || opts.draw_limit > 0 ? 1 : opts.tile_row_step;
-    hipLaunchKernelGGL(block_flags_kernel, dim3((unsigned)((nblk + 255) / 256), (unsigned)views), dim3(256), 0, s, scene, kb, vstride, opts.tile_row_begin, row_step, dead);
+    const RowShard rs = opts.draw_limit > 0 ? RowShard{0, 1, 0} : row_shard_of(opts);
+    hipLaunchKernelGGL(block_flags_kernel, dim3((unsigned)((nblk + 255) / 256), (unsigned)views), dim3(256), 0, s, scene, kb, vstride, rs, dead);
 }
 
 int launch_block_visibility(const GsrScene &scene, const GsrCamera &cam, const GsrOptions &opts, unsigned char *dead, hipStream_t s)
@@ -831,7 +818,8 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera *cams, const GsrOpt
     GsrDebugOut d;
     memset(&d, 0, sizeof d);
     if (dbg) d = *dbg;
-    const int row_step = opts.tile_row_step < 1 ? 1 : opts.tile_row_step, packed = rect_fits_8bit(ws) ? 1 : 0;
+    const RowShard rs = row_shard_of(opts);
+    const int packed = rect_fits_8bit(ws) ? 1 : 0;
     const bool h16 = scene.sh_dtype == 1;
     // from how many visible gaussians per wave on the wave's SH rows are fetched whole through LDS (load_sh48_wave);
     // GsrOptions.sh_dense_min overrides it for experiments (65 = never).  Swept on the bench frame (file order / Morton order): >= 56: 0.273 / 0.216 ms,
@@ -849,11 +837,11 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera *cams, const GsrOpt
     }
 #define GSR_LAUNCH_PRE(DBG, H16, COL)                                                                                         \
     hipLaunchKernelGGL((preprocess_kernel<DBG, H16, COL>), dim3(grid), dim3(PRE_THREADS), 0, s, scene, k, opts.reference_compat,     \
-                       opts.no_footprint_cull, opts.tile_row_begin, row_step, keep_drawn, ws.rec, ws.rect,     \
+                       opts.no_footprint_cull, rs, keep_drawn, ws.rec, ws.rect,     \
                        ws.rect8[0], ws.key[0], d, reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, packed, sh_dense_min, DBG ? nullptr : blk_dead)
 #define GSR_LAUNCH_VIEWS(H16, COL)                                                                                            \
     hipLaunchKernelGGL((preprocess_views_kernel<H16, COL>), dim3(grid), dim3(PRE_THREADS), 0, s, scene, kb, views, ws.view_stride,     \
-                       opts.reference_compat, opts.no_footprint_cull, opts.tile_row_begin, row_step, keep_drawn, ws.rec, ws.rect,   \
+                       opts.reference_compat, opts.no_footprint_cull, rs, keep_drawn, ws.rec, ws.rect,   \
                        ws.rect8[0], ws.key[0], reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, packed, blk_dead)
     // debug outputs cover every gaussian: for a shard (below) that is a pass of its own, whose other outputs are then
     // overwritten
@@ -865,7 +853,7 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera *cams, const GsrOpt
         uint32_t *run_cnt = ws.blk_sum;
 #define GSR_LAUNCH_SHARD(H16, COL)                                                                                            \
     hipLaunchKernelGGL((shard_preprocess_kernel<H16, COL>), dim3(sgrid, (unsigned)views), dim3(256), 0, s, scene, kb, views, ws.view_stride, opts.reference_compat,             \
-                       opts.no_footprint_cull, opts.tile_row_begin, row_step, ws.rec, ws.rect, ws.key[1], ws.val[1], ws.rect8[1], \
+                       opts.no_footprint_cull, rs, ws.rec, ws.rect, ws.key[1], ws.val[1], ws.rect8[1], \
                        run_cnt, reinterpret_cast<uint32_t *>(ws.ctrl), ctrl_reset_words, packed, blk_dead)
         if (h16) { if (colour) GSR_LAUNCH_SHARD(true, true); else GSR_LAUNCH_SHARD(true, false); }
         else { if (colour) GSR_LAUNCH_SHARD(false, true); else GSR_LAUNCH_SHARD(false, false); }

@@ -21,15 +21,26 @@ TILE = 16
 
 
 class TileRowPlan:
-    """Which tile rows each rank owns, and where its strip rows land in the frame."""
+    """Which tile rows each rank owns, and where its strip rows land in the frame.
 
-    def __init__(self, height: int, width: int, world: int):
+    `block` = 2 (default): PAIRS of rows — the two tile rows of one 32x32 binning cell — interleaved (rank r: rows 2r, 2r + 1,
+    2r + 2 world, ...; GsrOptions.tile_row_block): a rank bins and sorts only the cells it owns, and fewer gaussians reach it.  `block` = 1:
+    single tile rows (rank r: rows r, r + world, ...; rounds 1-4): two ranks share every cell row, each emitting and sorting all its
+    pairs; the ranks' row counts then differ by one at most instead of two.  Same frame either way.  Measured, bicycle stand-in at 1080p,
+    slowest rank, ms per frame (tools/shard_timing.py, block 1 / 2): G = 2: 0.368 / 0.326, 4: 0.247 / 0.224, 8: 0.170 / 0.152."""
+
+    def __init__(self, height: int, width: int, world: int, block: int = 2):
         if world < 1:
             raise ValueError("world must be >= 1")
-        self.height, self.width, self.world = int(height), int(width), int(world)
+        if block not in (1, 2):
+            raise ValueError("block must be 1 (single tile rows) or 2 (pairs of rows)")
+        self.height, self.width, self.world, self.block = int(height), int(width), int(world), int(block)
         self.tiles_y = (self.height + TILE - 1) // TILE
-        self.rows = [list(range(r, self.tiles_y, self.world)) for r in range(self.world)]
+        self.rows = [[t for t in range(self.tiles_y) if (t // self.block) % self.world == r] for r in range(self.world)]
         self.max_rows = max(1, max(len(x) for x in self.rows))
+        # frame tile row t <- strip row index_of[t] of rank owner[t]
+        self.owner = [(t // self.block) % self.world for t in range(self.tiles_y)]
+        self.index_of = [self.rows[self.owner[t]].index(t) for t in range(self.tiles_y)]
 
     def strip_shape(self, rank: int):
         """Shape of rank's compact strip as libgsr writes it (output_layout = 2)."""
@@ -40,7 +51,17 @@ class TileRowPlan:
         return (self.max_rows * TILE, self.width, 3)
 
     def shard_options(self, rank: int):
-        return dict(tile_row_begin=rank, tile_row_step=self.world, output_layout=2)
+        return dict(tile_row_begin=rank, tile_row_step=self.world, output_layout=2, tile_row_block=self.block)
+
+    def _scatter_rows(self, grid: torch.Tensor, strips: List[torch.Tensor]):
+        for r, s in enumerate(strips):
+            k = len(self.rows[r])
+            if k:
+                rows = s[: k * TILE].view(k, TILE, self.width, 3)
+                if self.block == 1:
+                    grid[r::self.world] = rows
+                else:
+                    grid[torch.as_tensor(self.rows[r], device=grid.device)] = rows
 
     def assemble(self, strips: List[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """strips[r]: padded strip of rank r -> frame [H,W,3]."""
@@ -49,18 +70,10 @@ class TileRowPlan:
         if out is None:
             out = torch.empty((self.height, self.width, 3), dtype=ref.dtype, device=ref.device)
         if padded_h == self.height:
-            grid = out.view(self.tiles_y, TILE, self.width, 3)
-            for r, s in enumerate(strips):
-                k = len(self.rows[r])
-                if k:
-                    grid[r::self.world] = s[: k * TILE].view(k, TILE, self.width, 3)
+            self._scatter_rows(out.view(self.tiles_y, TILE, self.width, 3), strips)
             return out
         full = torch.empty((padded_h, self.width, 3), dtype=ref.dtype, device=ref.device)
-        grid = full.view(self.tiles_y, TILE, self.width, 3)
-        for r, s in enumerate(strips):
-            k = len(self.rows[r])
-            if k:
-                grid[r::self.world] = s[: k * TILE].view(k, TILE, self.width, 3)
+        self._scatter_rows(full.view(self.tiles_y, TILE, self.width, 3), strips)
         out.copy_(full[: self.height])
         return out
 
@@ -72,7 +85,8 @@ class TileRowPlan:
         strip = frame.new_zeros(self.padded_shape())
         k = len(self.rows[rank])
         if k:
-            strip[: k * TILE] = full.view(self.tiles_y, TILE, self.width, 3)[rank::self.world].reshape(k * TILE, self.width, 3)
+            idx = torch.as_tensor(self.rows[rank], device=frame.device)
+            strip[: k * TILE] = full.view(self.tiles_y, TILE, self.width, 3)[idx].reshape(k * TILE, self.width, 3)
         return strip
 
 
@@ -99,10 +113,9 @@ class FrameGather:
                 # G x V strips is ONE index_select (one kernel, one Python call per batch on the root) instead of G x V copies
                 self._recv_all = [torch.zeros((plan.world, V) + plan.padded_shape(), dtype=dtype, device=device) for _ in range(buffers)]
                 self.recvs = [[ra[r] for r in range(plan.world)] for ra in self._recv_all]
-                t = torch.arange(plan.tiles_y)
                 k = torch.arange(V)
-                # (view k, frame tile row t) <- wire row of rank t % world, view k, its row t // world
-                src = ((t % plan.world)[None, :] * V + k[:, None]) * plan.max_rows + (t // plan.world)[None, :]
+                # (view k, frame tile row t) <- wire row of rank owner[t], view k, its strip row index_of[t]
+                src = (torch.as_tensor(plan.owner)[None, :] * V + k[:, None]) * plan.max_rows + torch.as_tensor(plan.index_of)[None, :]
                 self._row_src = src.reshape(-1).to(device)
 
     @property

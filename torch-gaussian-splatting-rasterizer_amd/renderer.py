@@ -221,7 +221,8 @@ def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_r
                  output_layout: int = 0, no_footprint_cull: bool = False, blend_impl: int = 0, draw_limit: int = 0,
                  output_bf16: bool = False, depth_sort_passes: int = 0, keep_flags: bool = False, accum_bf16: bool = False,
                  saturation_rule: int = 0, fine_binning: bool = False, shard_preprocess: int = 0, blend_pipe_tiles: int = 0,
-                 sh_dense_min: int = 0, colour_stage: int = 0, no_order_hint: bool = False, batch_views: int = 0) -> GsrOptions:
+                 sh_dense_min: int = 0, colour_stage: int = 0, no_order_hint: bool = False, batch_views: int = 0,
+                 tile_row_block: int = 0) -> GsrOptions:
     o = _lib.default_options()
     o.reference_compat = 1 if reference_compat else 0
     o.early_out_T = float(early_out_T)
@@ -243,12 +244,20 @@ def make_options(reference_compat: bool = True, early_out_T: float = 0.0, tile_r
     o.no_order_hint = 1 if no_order_hint else 0   # blend launch order by list length alone (default: by what each tile staged last frame)
     o.colour_stage = int(colour_stage)            # 0: sh_to_rgb when a tile first stages the gaussian (blend); 1: for every visible gaussian (preprocess)
     o.batch_views = int(batch_views)              # render_batch: at most this many views per launch sequence (0: as many as the workspace has slices)
+    o.tile_row_block = int(tile_row_block)        # tile-row shards: 0 / 1 = single rows interleave, 2 = pairs of rows (whole 32x32 cell rows)
     return o
 
 
-def shard_rows(height: int, begin: int, step: int) -> int:
+def shard_row_list(height: int, begin: int, step: int, block: int = 1):
+    """The tile rows a tile-row shard owns, ascending = its strip rows (GsrOptions.tile_row_begin / _step / _block: blocks of `block`
+    consecutive tile rows, block b is the shard's when b % step == begin)."""
     tiles_y = (height + TILE - 1) // TILE
-    return len(range(begin, tiles_y, max(step, 1)))
+    block = 2 if block == 2 else 1
+    return [t for t in range(tiles_y) if (t // block) % max(step, 1) == (begin if step > 1 else 0)]
+
+
+def shard_rows(height: int, begin: int, step: int, block: int = 1) -> int:
+    return len(shard_row_list(height, begin, step, block))
 
 
 class Rasterizer:
@@ -298,7 +307,7 @@ class Rasterizer:
             return (cam.height, cam.width, 3), (cam.height, cam.width)
         if opts.output_layout == 1:
             return (cam.width, cam.height, 3), (cam.width, cam.height)
-        rows = shard_rows(cam.height, opts.tile_row_begin, opts.tile_row_step) * TILE
+        rows = shard_rows(cam.height, opts.tile_row_begin, opts.tile_row_step, opts.tile_row_block) * TILE
         return (rows, cam.width, 3), (rows, cam.width)
 
     def bounded(self, opts: Optional[GsrOptions] = None) -> GsrOptions:
