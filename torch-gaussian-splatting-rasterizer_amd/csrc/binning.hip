@@ -40,6 +40,11 @@ namespace gsr {
 #define GSR_CULL_MIN_TILES 8
 #endif
 constexpr uint32_t CULL_MIN_TILES = GSR_CULL_MIN_TILES;
+// most workgroups of the count / emit grids per view (the macro: tools/ A/B builds)
+#ifndef GSR_EMIT_GRID_CAP
+#define GSR_EMIT_GRID_CAP 8192
+#endif
+constexpr int EMIT_GRID_CAP = GSR_EMIT_GRID_CAP;
 
 // The rank's rows of a rect: strip index (RowShard::rows_before) of the first of its rows in [ty0, ty1) and how many; row k of them is
 // sh.row_at(first + k).  (A RowShard at tile level, or — coarse binning — at the level of the 32x32 cells.)
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t
                                                                   const FrameCtrl *ctrl, const ushort4 *__restrict__ rect, RowShard sh,
                                                                   uint32_t *__restrict__ blk_sum, uint2 *__restrict__ ranges,
                                                                   int n_tiles, uint32_t draw_limit, uint2 *__restrict__ cranges, int n_ctiles,
-                                                                  FrameCtrl *ctrl_w, uint32_t ent_off, int nblk_n, size_t vstride)
+                                                                  FrameCtrl *ctrl_w, uint32_t ent_off, int nblk_n, int grid_wgs, size_t vstride)
 {
     id_a = view_slice(id_a, vstride); id_b = view_slice(id_b, vstride); r8_a = view_slice(r8_a, vstride); r8_b = view_slice(r8_b, vstride);
     ctrl = view_slice(ctrl, vstride); rect = view_slice(rect, vstride); blk_sum = view_slice(blk_sum, vstride); ranges = view_slice(ranges, vstride);
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t
     const uint32_t n = ctrl->n_visible;
     const uint32_t t = blockIdx.x * EMIT_THREADS + threadIdx.x;
     // threads in the grid (not gridDim.x: that would pull in the hidden kernarg block)
-    const uint32_t stride = (uint32_t)((nblk_n + COUNT_BLOCKS_PER_WG - 1) / COUNT_BLOCKS_PER_WG) * EMIT_THREADS;
+    const uint32_t stride = (uint32_t)grid_wgs * EMIT_THREADS;
     if (COARSE) {  // the cell ranges are rebuilt every frame too, and the expansion totals E with atomics
         for (uint32_t c = t; c < (uint32_t)n_ctiles; c += stride) cranges[c] = make_uint2(0u, 0u);
         if (t == 0) { ctrl_w->n_pairs = 0u; ctrl_w->ent_off = ent_off; }
@@ -112,10 +117,13 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t
     const bool odd = (ctrl->sort_passes & 1u) != 0;
     const uint32_t *sorted_ids = odd ? id_b : id_a, *sorted_rect8 = odd ? r8_b : r8_a;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t blk = blockIdx.x * COUNT_BLOCKS_PER_WG + (uint32_t)wave;  // this wave's emit block
-    if (blk >= (uint32_t)nblk_n) return;                                     // wave-uniform
-    const uint32_t r0 = blk * EMIT_THREADS + (uint32_t)lane * 4u;            // r = rank in the draw order
     const uint32_t lim = n < draw_limit ? n : draw_limit;
+    // this wave's emit blocks: the grid is capped (launch_binning) and strides over the blocks the frame HAS — n_visible is only known
+    // here; a grid sized by the bound n >= V spent most of the kernel launching waves that had nothing to count (a rank of 8 shards:
+    // 24 K workgroups for 2.4 K blocks)
+    for (uint32_t blk = blockIdx.x * COUNT_BLOCKS_PER_WG + (uint32_t)wave; blk < (uint32_t)nblk_n && blk * EMIT_THREADS < n;  // wave-uniform
+         blk += (uint32_t)grid_wgs * COUNT_BLOCKS_PER_WG) {
+    const uint32_t r0 = blk * EMIT_THREADS + (uint32_t)lane * 4u;            // r = rank in the draw order
     uint32_t cnt = 0;
     if (r0 < lim) {
         int first;
@@ -134,6 +142,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_count_kernel(const uint32_t
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d, 64);
     if (lane == 0) blk_sum[blk] = cnt;
+    }
 }
 
 // Single workgroup (1024 threads): exclusive scan of blk_sum[0..nblk) in place; totals into ctrl.  Sixteen
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
                                                                  const uint32_t *blk_off, uint32_t max_pairs,
                                                                  KeyT *__restrict__ pkey, uint32_t *__restrict__ pval,
                                                                  uint32_t draw_limit, RowShard tsh, uint32_t *blk_entries /* = blk_off: no __restrict__ on either */,
-                                                                 size_t vstride)
+                                                                 int grid_wgs, size_t vstride)
 {
     id_a = view_slice(id_a, vstride); id_b = view_slice(id_b, vstride); r8_a = view_slice(r8_a, vstride); r8_b = view_slice(r8_b, vstride);
     ctrl = view_slice(ctrl, vstride); rect = view_slice(rect, vstride); rec = view_slice(rec, vstride); blk_off = view_slice(blk_off, vstride);
@@ -233,15 +242,18 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
     __shared__ float4 s_q0[EMIT_THREADS];
     __shared__ float4 s_q1[EMIT_THREADS];
     __shared__ uint32_t s_fine[COARSE ? EMIT_THREADS : 1];  // coarse: the gaussian's packed TILE rect
-    // the workgroup's slot base first: its load is independent of everything below and would otherwise wait behind two barriers
-    // (saturated at 2^32 - 1 by the scan: then nothing below is written)
-    const unsigned long long base = blk_off[blockIdx.x];
     const uint32_t n = ctrl->n_visible;
     const bool odd = (ctrl->sort_passes & 1u) != 0;
     const uint32_t *sorted_ids = odd ? id_b : id_a, *sorted_rect8 = odd ? r8_b : r8_a;
     const int tid = threadIdx.x;
-    const uint32_t r = blockIdx.x * EMIT_THREADS + tid;
-    if (blockIdx.x * EMIT_THREADS >= n) return;  // uniform
+    // the grid is capped (launch_binning) and strides over the emit blocks the frame has: sized by the bound n >= V it launched more
+    // workgroups that found nothing to do than ones that did (n_visible is only known here)
+#pragma unroll 1
+    for (uint32_t blk = blockIdx.x; blk * EMIT_THREADS < n; blk += (uint32_t)grid_wgs) {  // uniform
+    // the block's slot base first: its load is independent of everything below and would otherwise wait behind two barriers
+    // (saturated at 2^32 - 1 by the scan: then nothing below is written)
+    const unsigned long long base = blk_off[blk];
+    const uint32_t r = blk * EMIT_THREADS + tid;
     uint32_t cnt = 0, g = 0;
     int first = 0;
     ushort4 rc = make_ushort4(0, 0, 0, 0);
@@ -308,12 +320,14 @@ __global__ __launch_bounds__(EMIT_THREADS) void pair_emit_kernel(const uint32_t 
         }
     }
     if (COARSE) {  // E = the sum of these partials, taken by gsr_read_stats (an atomic per workgroup here would serialise on one word).
-        // The workgroup's scanned offset (blk_off[blockIdx.x], read above by this workgroup alone) is no longer needed: its slot
+        // The block's scanned offset (blk_off[blk], read above by this workgroup alone) is no longer needed: its slot
         // carries the partial.
         __syncthreads();
         uint32_t tot;
         block_excl_scan_256(entries, scratch, &tot);
-        if (tid == 0) blk_entries[blockIdx.x] = tot;
+        if (tid == 0) blk_entries[blk] = tot;
+    }
+    __syncthreads();  // the block's lists in LDS are done with
     }
 }
 
@@ -414,15 +428,17 @@ int launch_binning(const GsrOptions &opts, const Workspace &ws, hipStream_t s)
     const uint32_t cap = (uint32_t)ws.max_pairs;
     const uint32_t limit = opts.draw_limit > 0 ? (uint32_t)opts.draw_limit : 0xFFFFFFFFu;
     const int nblk_n = (int)((ws.n + EMIT_THREADS - 1) / EMIT_THREADS);                       // emit blocks (the bound: n >= V)
-    const int nblk_count = (nblk_n + COUNT_BLOCKS_PER_WG - 1) / COUNT_BLOCKS_PER_WG;          // the count kernel: one wave per emit block
-                                                                                              // (it also zeroes ranges[] / cranges[], grid-stride)
+    // the count kernel: one wave per emit block (it also zeroes ranges[] / cranges[], grid-stride); both grids are capped and stride
+    // over the blocks the frame has — V is known on the device only
+    const int nblk_count = std::min((nblk_n + COUNT_BLOCKS_PER_WG - 1) / COUNT_BLOCKS_PER_WG, EMIT_GRID_CAP / COUNT_BLOCKS_PER_WG);
+    const int nblk_emit = std::min(nblk_n, EMIT_GRID_CAP);
 #define GSR_COUNT(P, C) hipLaunchKernelGGL((pair_count_kernel<P, C>), dim3(nblk_count, nv), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
                                            ws.ctrl, ws.rect, C ? csh : sh, ws.blk_sum, ws.ranges, n_tiles, limit, ws.cranges, n_ctiles, ws.ctrl, \
-                                           C ? (uint32_t)(reinterpret_cast<const char *>(ws.blk_sum) - reinterpret_cast<const char *>(ws.ctrl)) : 0u, nblk_n, vs)
+                                           C ? (uint32_t)(reinterpret_cast<const char *>(ws.blk_sum) - reinterpret_cast<const char *>(ws.ctrl)) : 0u, nblk_n, nblk_count, vs)
     const bool k16 = pair_keys_16bit(tk.bits_x + tk.bits_y);  // two-byte keys in memory when they fit (sort.hip)
-#define GSR_EMIT_T(P, C, T) hipLaunchKernelGGL((pair_emit_kernel<P, C, T>), dim3(nblk_n, nv), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
+#define GSR_EMIT_T(P, C, T) hipLaunchKernelGGL((pair_emit_kernel<P, C, T>), dim3(nblk_emit, nv), dim3(EMIT_THREADS), 0, s, ws.val[0], ws.val[1], ws.rect8[0], ws.rect8[1], \
                                           ws.ctrl, ws.rect, C ? csh : sh, tk.bits_x, tk.grid_y, ws.rec, ws.blk_sum, cap, reinterpret_cast<T *>(ws.pkey[0]), ws.pval[0], limit, \
-                                          sh, ws.blk_sum, vs)
+                                          sh, ws.blk_sum, nblk_emit, vs)
 #define GSR_EMIT(P, C) do { if (k16) GSR_EMIT_T(P, C, uint16_t); else GSR_EMIT_T(P, C, uint32_t); } while (0)
     if (tk.coarse) GSR_COUNT(true, true); else if (packed_rect) GSR_COUNT(true, false); else GSR_COUNT(false, false);
     hipLaunchKernelGGL(pair_scan_kernel, dim3(1, nv), dim3(1024), 0, s, ws.blk_sum, nblk_n, ws.ctrl, cap, vs);
