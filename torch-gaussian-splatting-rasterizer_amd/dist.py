@@ -1,8 +1,9 @@
 """Tile-row sharding of one frame over the GPUs of a node + the framebuffer gather.
 
 The reference has no distributed code.  A frame shards naturally by 16x16 tile rows: every pixel depends only
-on the gaussians binned to its tile, so rank r bins and blends tile rows r, r+G, r+2G, ... (interleaved, for load
-balance) into a compact strip [rows_r*16, W, 3], and ONE collective — a gather to rank 0 (RCCL over xGMI on the
+on the gaussians binned to its tile, so rank r bins and blends every G-th PAIR of tile rows — 2r, 2r+1, 2r+2G, ...: whole rows of
+the 32x32 cells the binning works in, interleaved for load balance (TileRowPlan; single rows r, r+G, ... until round 4) — into a
+compact strip [rows_r*16, W, 3], and ONE collective — a gather to rank 0 (RCCL over xGMI on the
 GPU box: each peer->root transfer rides its own link) — exchanges the strips.  Per-pixel blend order does not
 depend on the sharding, so the assembled frame is bit-identical to the single-GPU frame.
 
