@@ -829,7 +829,8 @@ int launch_preprocess(const GsrScene &scene, const GsrCamera *cams, const GsrOpt
     const int keep_drawn = opts.draw_limit > 0 ? 1 : 0;
     // block-level culling: the flags first (not for the debug pass, whose outputs cover every gaussian; not for the three-phase shard
     // kernel either: its phase 1 already leaves a gaussian after 24 B, and measured on rank 3 of 8 of the bench frame the flags
-    // kernel costs what the skipped loads return — 5.4 + 84.2 us against 82.6 us without)
+    // kernel costs what the skipped loads return — 5.4 + 84.2 us against 82.6 us without; with rows in pairs, rank 2 of 8, four views:
+    // 9.4 + 218.7 against 222)
     const unsigned char *blk_dead = nullptr;
     if (scene.block_bounds != nullptr && !dbg && !shard_compact(opts)) {
         launch_block_flags(scene, kb, views, ws.view_stride, opts, ws.blk_dead, s);
