@@ -27,7 +27,8 @@ extern "C" {
 
 #define GSR_VERSION 600 /* 0.6.0: several views per launch sequence — gsr_render_batch / gsr_render_batch_slots put as many views through ONE
                             preprocess / sort / blend launch sequence as the workspace holds slices of gsr_workspace_bytes() (GsrOptions.batch_views
-                            caps it); gsr_blend takes the scene again (NULL = what gsr_preprocess left in the workspace).  0.5.0: GsrOptions.saturation_rule (the exact colour-saturation early-out), the four environment switches became GsrOptions
+                            caps it); gsr_blend takes the scene again (NULL = what gsr_preprocess left in the workspace); GsrScene.block_bounds + gsr_scene_bounds /
+                            gsr_block_visibility (block-level culling); GsrOptions.tile_row_block (tile-row shards in pairs of rows).  0.5.0: GsrOptions.saturation_rule (the exact colour-saturation early-out), the four environment switches became GsrOptions
                             fields (the library reads no environment and holds no function statics), GsrOptions.colour_stage / no_order_hint,
                             GsrStats.colour_evals, + gsr_scene_order.  0.4.0: GsrOptions.keep_flags, GsrOptions.accum_dtype; GsrStats.sort_passes reports the worst frame when the bound was exceeded; blend_impl 2
                             (matrix-pipe experiment) removed; the frame clear covers every word of the control block.  0.3.0: GsrOptions.depth_sort_passes, GsrStats.sort_passes, GSR_ERR_SORT_PASSES.  0.2.1: + gsr_render_batch_slots.
