@@ -64,7 +64,10 @@ struct alignas(16) GaussRec {
 constexpr int DEPTH_SORT_THREADS = 512;  // depth sort: 9-bit digits on 8192-key tiles (radix.h)
 constexpr int PAIR_SORT_THREADS = 256;   // pair sort: <= 8-bit digits on 4096-pair tiles
 constexpr int DEPTH_SORT_ITEMS = 16;     // keys per thread per pass (2048-key tiles measured slower: fixed per-workgroup costs dominate)
-constexpr int DEPTH_SORT_ITEMS_SHARD = 8;  // a multi-GPU rank's compact records (~0.8 M at G = 8): 4096-key tiles, twice the workgroups, half the serial chain each
+#ifndef GSR_DS_SHARD_ITEMS
+#define GSR_DS_SHARD_ITEMS 8
+#endif
+constexpr int DEPTH_SORT_ITEMS_SHARD = GSR_DS_SHARD_ITEMS;  // (the macro: tools/ A/B builds; 2048-key tiles measured on a rank of 8 with rows in pairs: 0.138 against 0.126 ms per frame)  // a multi-GPU rank's compact records (~0.8 M at G = 8): 4096-key tiles, twice the workgroups, half the serial chain each
 constexpr int PAIR_SORT_ITEMS = 16;
 constexpr int EMIT_THREADS = 256;                     // threads per workgroup in the binning kernels
 constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
