@@ -47,7 +47,8 @@ for G in (1, 2, 4, 8) if only is None else (only[0],):
     one, many, vis, pairs = [], [], [], []
     for r in range(G) if only is None else (only[1],):
         impl = int(os.environ.get("GSR_BLEND_IMPL", "0"))  # A/B of blend kernels
-        opts = renderer.make_options(blend_impl=impl, **plan.shard_options(r)) if G > 1 else renderer.make_options(blend_impl=impl)
+        pre = int(os.environ.get("GSR_SHARD_PRE", "0"))  # GsrOptions.shard_preprocess: 0 auto, 1 whole-frame kernel, 2 three-phase kernel
+        opts = renderer.make_options(blend_impl=impl, shard_preprocess=pre, **plan.shard_options(r)) if G > 1 else renderer.make_options(blend_impl=impl)
         shape = plan.strip_shape(r) if G > 1 else (H, W, 3)
         fif = renderer.FramesInFlight(scene, slots=SLOTS, views=VIEWS)
         fif.set_max_pairs(fif.rasterizers[0].fit_pairs(cam, opts))
