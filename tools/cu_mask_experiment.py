@@ -72,15 +72,18 @@ sets = {
     "even | odd CUs": [set(range(0, 256, 2)), set(range(1, 256, 2))],
     "interleaved by 8: XCD-like": [set(i for i in range(256) if (i % 8) < 4), set(i for i in range(256) if (i % 8) >= 4)],
     "three quarters | quarter": [set(range(0, 192)), set(range(192, 256))],
+    "even | odd, two streams each": [set(range(0, 256, 2)), set(range(1, 256, 2)), set(range(0, 256, 2)), set(range(1, 256, 2))],
+    "thirds (CU % 3)": [set(i for i in range(256) if i % 3 == r) for r in range(3)],
+    "4 of 8 | other 4, two streams each": [set(i for i in range(256) if (i % 8) < 4), set(i for i in range(256) if (i % 8) >= 4)] * 2,
 }
 for label, cams in (("camera set", ring), ("one camera", ring[:1])):
     print(label, flush=True)
     for name, masks in sets.items():
         try:
             streams = None if masks is None else [masked_stream(m) for m in masks]
-            S = 2
+            S = 2 if masks is None else len(masks)
             run(streams, S, 32, cams)
-            print(f"  K={K} S={S} {name:32s} {run(streams, S, FRAMES, cams):7.1f} frames/s", flush=True)
+            print(f"  K={K} S={S} {name:36s} {run(streams, S, FRAMES, cams):7.1f} frames/s", flush=True)
         except Exception as e:  # noqa: BLE001
             print(f"  {name}: {e}", flush=True)
     # reference point: three shared streams (bench.py's default number of batches in flight)
