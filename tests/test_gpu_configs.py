@@ -187,8 +187,8 @@ def test_configs4_box_4k_exactness_properties(G, box4k):
 
 def test_configs3_bicycle_camera_set_in_8_tile_row_shards(G):
     """configs[3] at its own workload, on one GPU: the bicycle stand-in (6 131 954 gaussians) at 1920x1080 over the WHOLE
-    25-camera set, every frame rendered as the 8 interleaved tile-row shards an 8-GPU node would render (TileRowPlan's default: rank r =
-    the pairs of tile rows 2r, 2r+1, 2r+16, ...; the rank's loop is bench.py's: frames in flight on separate streams, strips into padded wire buffers,
+    25-camera set, every frame rendered as the 8 interleaved tile-row shards an 8-GPU node would render (TileRowPlan's default: a rank owns every
+    8th PAIR of tile rows, rank 0 the ones no remainder falls to; the rank's loop is bench.py's: frames in flight on separate streams, strips into padded wire buffers,
     bounds learned on camera 0 and passed explicitly, ONE stats() per slot after the run) and put together by
     TileRowPlan.assemble (what rank 0 does after the RCCL gather).
       (i)   every camera's assembled frame is bit-identical to its unsharded frame;

@@ -1,7 +1,7 @@
 """Tile-row sharding of one frame over the GPUs of a node + the framebuffer gather.
 
 The reference has no distributed code.  A frame shards naturally by 16x16 tile rows: every pixel depends only
-on the gaussians binned to its tile, so rank r bins and blends every G-th PAIR of tile rows — 2r, 2r+1, 2r+2G, ...: whole rows of
+on the gaussians binned to its tile, so a rank bins and blends every G-th PAIR of tile rows — 2b, 2b+1 for b = G-1-r, 2G-1-r, ...: whole rows of
 the 32x32 cells the binning works in, interleaved for load balance (TileRowPlan; single rows r, r+G, ... until round 4) — into a
 compact strip [rows_r*16, W, 3], and ONE collective — a gather to rank 0 (RCCL over xGMI on the
 GPU box: each peer->root transfer rides its own link) — exchanges the strips.  Per-pixel blend order does not
@@ -24,9 +24,9 @@ TILE = 16
 class TileRowPlan:
     """Which tile rows each rank owns, and where its strip rows land in the frame.
 
-    `block` = 2 (default): PAIRS of rows — the two tile rows of one 32x32 binning cell — interleaved (rank r: rows 2r, 2r + 1,
-    2r + 2 world, ...; GsrOptions.tile_row_block): a rank bins and sorts only the cells it owns, and fewer gaussians reach it.  `block` = 1:
-    single tile rows (rank r: rows r, r + world, ...; rounds 1-4): two ranks share every cell row, each emitting and sorting all its
+    `block` = 2 (default): PAIRS of rows — the two tile rows of one 32x32 binning cell — interleaved (rank r: blocks b = world - 1 - r,
+    2 world - 1 - r, ..., i.e. rows 2b, 2b + 1; GsrOptions.tile_row_block): a rank bins and sorts only the cells it owns, and fewer gaussians reach it.  `block` = 1:
+    single tile rows (rank r: rows world - 1 - r, 2 world - 1 - r, ...; rounds 1-4 with r in place of world - 1 - r): two ranks share every cell row, each emitting and sorting all its
     pairs; the ranks' row counts then differ by one at most instead of two.  Same frame either way.  Measured, bicycle stand-in at 1080p,
     slowest rank, ms per frame (tools/shard_timing.py, block 1 / 2): G = 2: 0.368 / 0.326, 4: 0.247 / 0.224, 8: 0.170 / 0.152."""
 
@@ -37,10 +37,13 @@ class TileRowPlan:
             raise ValueError("block must be 1 (single tile rows) or 2 (pairs of rows)")
         self.height, self.width, self.world, self.block = int(height), int(width), int(world), int(block)
         self.tiles_y = (self.height + TILE - 1) // TILE
-        self.rows = [[t for t in range(self.tiles_y) if (t // self.block) % self.world == r] for r in range(self.world)]
+        # rank r takes the blocks b with b % world == world - 1 - r: the blocks left over when world does not divide their number go to
+        # the LAST ranks, so that rank 0 — which also receives and de-interleaves everybody's strips — never carries an extra one
+        self.begin = [self.world - 1 - r for r in range(self.world)]
+        self.rows = [[t for t in range(self.tiles_y) if (t // self.block) % self.world == self.begin[r]] for r in range(self.world)]
         self.max_rows = max(1, max(len(x) for x in self.rows))
         # frame tile row t <- strip row index_of[t] of rank owner[t]
-        self.owner = [(t // self.block) % self.world for t in range(self.tiles_y)]
+        self.owner = [self.world - 1 - (t // self.block) % self.world for t in range(self.tiles_y)]
         self.index_of = [self.rows[self.owner[t]].index(t) for t in range(self.tiles_y)]
 
     def strip_shape(self, rank: int):
@@ -52,7 +55,7 @@ class TileRowPlan:
         return (self.max_rows * TILE, self.width, 3)
 
     def shard_options(self, rank: int):
-        return dict(tile_row_begin=rank, tile_row_step=self.world, output_layout=2, tile_row_block=self.block)
+        return dict(tile_row_begin=self.begin[rank], tile_row_step=self.world, output_layout=2, tile_row_block=self.block)
 
     def _scatter_rows(self, grid: torch.Tensor, strips: List[torch.Tensor]):
         for r, s in enumerate(strips):
@@ -60,7 +63,7 @@ class TileRowPlan:
             if k:
                 rows = s[: k * TILE].view(k, TILE, self.width, 3)
                 if self.block == 1:
-                    grid[r::self.world] = rows
+                    grid[self.begin[r]::self.world] = rows
                 else:
                     grid[torch.as_tensor(self.rows[r], device=grid.device)] = rows
 
