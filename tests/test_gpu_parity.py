@@ -635,6 +635,35 @@ def test_tile_row_shards_reassemble_bit_exactly(G, step, block):
     assert pairs >= R.last_stats["n_pairs"] > 0                 # shards cull per-tile a little less (smaller rects)
 
 
+def test_shards_of_a_frame_with_fewer_row_blocks_than_ranks(G):
+    """A 200x40 frame has three tile rows = two cell rows: of 8 ranks most own nothing.  Their calls must render an empty strip and
+    leave the others' rows alone; the plan's strips still assemble into the frame (both row plans, both preprocess kernels, a batch)."""
+    from gsr_amd import dist as gdist
+
+    cols, cam, _ = _medium(G, n=30_000, W=200, H=40)
+    scene = G.renderer.GaussianScene.from_columns(cols)
+    R = G.renderer.Rasterizer(scene)
+    full = R.render(cam)
+    assert bool(full.any())
+    for block in (1, 2):
+        plan = gdist.TileRowPlan(40, 200, 8, block)
+        assert sum(1 for rows in plan.rows if not rows) == (5 if block == 1 else 6)
+        strips = []
+        for r in range(8):
+            so = plan.shard_options(r)
+            strip = R.render(cam, G.renderer.make_options(**so))
+            assert tuple(strip.shape) == plan.strip_shape(r)
+            if plan.rows[r]:
+                assert torch.equal(G.renderer.Rasterizer(scene, views=2).render_batch([cam, cam], G.renderer.make_options(**so))[1], strip)
+                assert torch.equal(R.render(cam, G.renderer.make_options(shard_preprocess=1, **so)), strip)
+            else:
+                assert R.last_stats["n_visible"] == 0 and R.last_stats["n_pairs"] == 0
+            padded = torch.zeros(plan.padded_shape(), device="cuda")
+            padded[: strip.shape[0]] = strip
+            strips.append(padded)
+        assert torch.equal(plan.assemble(strips), full)
+
+
 def test_three_phase_shard_preprocess_on_its_other_paths(G):
     """preprocess.hip: ranks of 5+ shards find their gaussians with shard_preprocess_kernel (bound -> geometry -> colour, runs
     compacted for the depth sort).  test_tile_row_shards_reassemble_bit_exactly covers it at step 8 on the packed-rect fp32
