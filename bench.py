@@ -87,7 +87,7 @@ def parse():
                     help="single: every step renders --camera; all: steps cycle over the whole camera set (configs[3])")
     ap.add_argument("--input_dir", default="", help="real data: MipNeRF-360 scene dir with sparse/0/{images,cameras}.bin")
     ap.add_argument("--trained_model_path", default="", help="real data: INRIA model dir (point_cloud/iteration_30000/point_cloud.ply)")
-    ap.add_argument("--legs", default="configs2,early_out,camera_set,file_order,garden,box4k", help="extra legs at N=1 (comma list; '' = none)")
+    ap.add_argument("--legs", default="configs2,early_out,camera_set,shards8,file_order,garden,box4k", help="extra legs at N=1 (comma list; '' = none)")
     ap.add_argument("--scene-order", default="morton", choices=["morton", "file"],
                     help="how the loader lays the gaussians' arrays out in HBM: along a Morton curve of their means (renderer.GaussianScene "
                          "spatial_order=True: the same frame up to the mutual order of gaussians at exactly equal depth, which the reference "
@@ -588,6 +588,29 @@ def main():
             result["camera_set"] = {"cameras": len(ring), "frames_per_s": max(steps_leg, 50) / el, "ms_per_step": 1e3 * el / max(steps_leg, 50),
                                     "note": "not the headline: the same scene, a different camera of the 25-pose ring every frame (one GPU)"}
             del Rc
+
+        # (1c) one-GPU rehearsal of configs[3]'s 8-GPU sharding: the slowest and a typical rank's tile-row shard of the headline frame
+        # (dist.TileRowPlan's default plan; the loop a rank of `bench.py --gpus 8` runs — four views per launch sequence, three batches
+        # in flight — without the gather): what bounds the frame rate of the 8-GPU run from the render side
+        if "shards8" in legs and not real:
+            plan8 = gdist.TileRowPlan(H, W, 8)
+            heavy = max(range(8), key=lambda r: (len(plan8.rows[r]), r))
+            per_rank = {}
+            for r in sorted({0, heavy}):
+                s_opts = renderer.make_options(early_out_T=args.early_out_T, blend_impl=args.blend_impl, colour_stage=args.colour_stage,
+                                               **plan8.shard_options(r))
+                Rs = renderer.Rasterizer(scene)
+                Rs.max_pairs = max(Rs.fit_pairs(c, s_opts) for c in cams)
+                s_steps = max(steps_leg, 120)  # thirty batches: the fill and drain of the three slots weigh a few per cent
+                el = timed_frames(Rs, cams, s_opts, torch.empty(plan8.strip_shape(r), dtype=torch.float32, device=dev), s_steps, warm_leg, dev, 3, 4)
+                per_rank[r] = 1e3 * el / s_steps
+                del Rs
+            worst = max(per_rank.values())
+            result["shards8"] = {"ms_per_frame_by_rank": {str(r): v for r, v in per_rank.items()}, "tile_rows_by_rank": {str(r): len(plan8.rows[r]) for r in per_rank},
+                                 "slowest_ms_per_frame": worst, "frames_per_s_bound_at_8_gpus": 1e3 / worst, "views_per_launch": 4, "frames_in_flight": 3,
+                                 "note": "not the headline and not a multi-GPU measurement: ONE GPU renders rank 0's (the gather's root, eight tile rows) and the "
+                                         "heaviest rank's (ten tile rows) shard of the headline frame the way a rank of `bench.py --gpus 8` does, gather "
+                                         "excluded — the render-side bound of the 8-GPU frame rate (DESIGN.md section 6)"}
 
         # (2) BASELINE configs[2]: fp16 SH storage + bf16 frame store (accumulation stays fp32: bf16 accumulators measure 41 dB,
         # below the 50 dB bar).  PSNR below is against the fp32 oracle of the fp32 coefficients.
